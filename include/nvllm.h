@@ -1,0 +1,242 @@
+/*
+ * nvllm.h — C ABI of libnvllm_hip.so: the MI355X (gfx950) forward path that
+ * replaces nano-vllm-go's purego/tensor prefill + decode hot path.
+ *
+ * Drop-in boundary.  A Go maintainer binds these with cgo (stub in
+ * INTEGRATION.md) and implements nanovllm.ModelRunner on top of them; nothing
+ * else in nano-vllm-go changes.  Every entry point names the reference
+ * interface it replaces (file:line under the reference repository).
+ *
+ *   - plain C, opaque handles, plain pointers + sizes, no C++/torch types;
+ *   - every function returns 0 on success or a negative nvl_status; the text
+ *     of the last failure is available from nvl_last_error();
+ *   - the library never aborts where the reference panics (shape mismatch
+ *     tensor.go:64-68, RoPE overflow rope.go:84-86): those are error codes;
+ *   - host buffers are borrowed for the duration of the call only (cgo pointer
+ *     rules); results are written into caller-provided host buffers;
+ *   - a model handle owns one HIP stream and is NOT re-entrant (the reference's
+ *     engine is single-goroutine: nanovllm/llm_engine.go:62-98).
+ */
+#ifndef NVLLM_H
+#define NVLLM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVL_ABI_VERSION 1
+
+typedef enum nvl_status {
+    NVL_OK = 0,
+    NVL_ERR_INVALID = -1,      /* bad argument / shape mismatch (reference: panic tensor.go:64-68) */
+    NVL_ERR_POSITION = -2,     /* pos >= max_seq_len           (reference: panic rope.go:84-86)   */
+    NVL_ERR_UNKNOWN_SEQ = -3,  /* decode for a sequence with no cache slot                         */
+    NVL_ERR_NO_SLOT = -4,      /* all KV slots in use                                              */
+    NVL_ERR_OOM = -5,          /* hipMalloc failed                                                 */
+    NVL_ERR_HIP = -6,          /* any other HIP runtime error                                      */
+    NVL_ERR_STATE = -7,        /* call out of order (e.g. forward before finalize)                 */
+    NVL_ERR_NO_DEVICE = -8     /* no gfx950 device visible: the library has NO CPU fallback        */
+} nvl_status;
+
+/* ---- model description: flat mirror of tensor.ModelConfig (purego/tensor/config.go:58-122) ---- */
+enum { NVL_ATTN_MHA = 0, NVL_ATTN_MQA = 1, NVL_ATTN_GQA = 2 };        /* config.go:18-22 */
+enum { NVL_NORM_LAYER = 0, NVL_NORM_RMS = 1 };                        /* config.go:27-30 */
+enum { NVL_POS_LEARNED = 0, NVL_POS_ROPE = 1, NVL_POS_NONE = 2 };     /* config.go:35-40 */
+enum { NVL_ACT_GELU = 0, NVL_ACT_SWIGLU = 1 };                        /* config.go:45-48 */
+enum { NVL_BLOCK_SEQUENTIAL = 0, NVL_BLOCK_PARALLEL = 1 };            /* config.go:53-56 */
+
+typedef struct nvl_model_config {
+    int32_t vocab_size, hidden, num_layers, num_heads, num_kv_heads, head_dim;
+    int32_t ffn_dim, max_seq_len;
+    int32_t attention_type, norm_type, position_type, activation_type, block_style;
+    double  rope_base;       /* config.go:89; ignored for MQA, which hard-wires 10000 (mqa.go:35) */
+    float   norm_eps;
+    int32_t tied_embedding;
+    int32_t use_moe, num_experts, num_experts_per_tok;
+    float   embedding_multiplier, attention_multiplier, residual_multiplier, logits_scaling;
+} nvl_model_config;
+
+/* Arithmetic the device path computes in. */
+enum {
+    NVL_PRECISION_BF16 = 0, /* bf16 weights + bf16 GEMM/attention operands on MFMA, fp32 accumulate,
+                               fp32 residual stream / norms / softmax / RoPE (the product path)   */
+    NVL_PRECISION_F32  = 1  /* fp32 weights, fp32 operands everywhere (slow; the tight-tolerance
+                               parity mode used by the tests)                                     */
+};
+
+typedef struct nvl_runtime_opts {
+    int32_t device;            /* HIP device ordinal                                               */
+    int32_t precision;         /* NVL_PRECISION_*                                                  */
+    int32_t max_seqs;          /* KV slots (concurrent sequences); replaces the unbounded
+                                  map[int64]*KVCache of tensor_model_runner.go:13                  */
+    int32_t max_batch_tokens;  /* largest sum(seq_lens) one nvl_forward call may carry             */
+    int32_t tp_rank, tp_size;  /* tensor-parallel shard of this process (1 = none); consumer of the
+                                  reference's inert Config.TensorParallelSize (nanovllm/config.go:61) */
+    int32_t reserved[2];
+} nvl_runtime_opts;
+
+typedef struct nvl_model nvl_model;
+
+/* ---- tensors: the layout contract of generic_loader.go:353-604 ---- */
+typedef enum nvl_tensor_kind {
+    NVL_T_TOK_EMB = 0,     /* [V, H]                 TransformerModel.TokenEmbedding generic_model.go:8 */
+    NVL_T_POS_EMB,         /* [max_seq, H]           PosEmbedding                    generic_model.go:9 */
+    NVL_T_LM_HEAD,         /* IN_OUT: [H, V]         LMHead (omit when tied)         generic_model.go:18 */
+    NVL_T_FINAL_NORM_W,    /* [H]                    LNFinal.Weight                                  */
+    NVL_T_FINAL_NORM_B,    /* [H]  absent => RMSNorm LNFinal.Bias           tensor.go:197            */
+    /* per layer */
+    NVL_T_ATTN_NORM_W,     /* AttnLN (sequential) / InputLN (parallel)      generic_model.go:26-28   */
+    NVL_T_ATTN_NORM_B,
+    NVL_T_FFN_NORM_W,
+    NVL_T_FFN_NORM_B,
+    NVL_T_WQ,              /* IN_OUT: [H, nH*hd]     attention.go:12,200  mqa.go:14                  */
+    NVL_T_WK,              /* IN_OUT: [H, nKV*hd]    attention.go:13,201                             */
+    NVL_T_WV,
+    NVL_T_WKV,             /* IN_OUT: [H, 2*hd]      MQA fused K|V        mqa.go:15                  */
+    NVL_T_WO,              /* IN_OUT: [nH*hd, H]                                                     */
+    NVL_T_BQ, NVL_T_BK, NVL_T_BV, NVL_T_BO,   /* MHA biases               attention.go:19-23       */
+    NVL_T_W1,              /* IN_OUT: [H, 2F] gate|up (SwiGLU) or [H, F]   transformer.go:30        */
+    NVL_T_B1,
+    NVL_T_W2,              /* IN_OUT: [F, H]                                                         */
+    NVL_T_B2,
+    NVL_T_ROUTER,          /* IN_OUT: [H, E]                               moe.go:12                */
+    NVL_T_MOE_IN,          /* [E, 2I, H] exactly as the reference keeps it (un-transposed) moe.go:176 */
+    NVL_T_MOE_OUT,         /* [E, H, I]                                                              */
+    NVL_T_COUNT
+} nvl_tensor_kind;
+
+enum { NVL_DTYPE_F32 = 0, NVL_DTYPE_BF16 = 1, NVL_DTYPE_F16 = 2 };    /* generic_loader.go:645-663 */
+enum {
+    NVL_LAYOUT_IN_OUT = 0, /* [in, out]: what the reference holds after Transpose (generic_loader.go:398-403) */
+    NVL_LAYOUT_OUT_IN = 1  /* [out, in]: the checkpoint's own PyTorch layout, uploaded without the host transpose */
+};
+
+/* ---- lifecycle ---- */
+
+/* Replaces tensor.NewTransformerModel (generic_model.go:41-61) + the runner's model ownership
+ * (tensor_model_runner.go:21-33).  Fails with NVL_ERR_NO_DEVICE when no GPU is present. */
+int nvl_create(const nvl_model_config* cfg, const nvl_runtime_opts* opts, nvl_model** out);
+
+/* Replaces loadTensorFromData + the per-kind placement in loadAttention/loadFFN/loadMoE/loadNorm
+ * (generic_loader.go:353-604,619-671).  `data` may be a host or a device pointer.  2-D kinds
+ * take (rows, cols) in the order of `layout`; 1-D kinds rows = n, cols = 1; MoE kinds pass
+ * rows = E*out, cols = in. */
+int nvl_upload_tensor(nvl_model* m, int kind, int layer, const void* data, int dtype,
+                      int64_t rows, int64_t cols, int layout);
+
+/* Helpers for checkpoints that keep fused projections (generic_loader.go:674-765):
+ * GPT-2 c_attn [H, 3H] split by columns; Falcon query_key_value given in the reference's
+ * post-transpose form [H, (nH+2)*hd]; both fp32, host pointers. */
+int nvl_upload_gpt2_qkv(nvl_model* m, int layer, const float* c_attn_w, const float* c_attn_b);
+int nvl_upload_falcon_qkv(nvl_model* m, int layer, const float* qkv_in_out);
+
+/* Freezes weights into the kernels' layouts, builds RoPE tables (rope.go:18-50, in fp64 on the
+ * host exactly as the reference), allocates KV slots and workspaces. */
+int nvl_finalize(nvl_model* m);
+
+/* Replaces TensorModelRunner.Close (tensor_model_runner.go:114-117). */
+void nvl_destroy(nvl_model* m);
+
+/* ---- sequences: replace map[int64]*KVCache (tensor_model_runner.go:11-18,59-68,100-112) ---- */
+int nvl_seq_open(nvl_model* m, int64_t seq_id);     /* get-or-create a KV slot                     */
+int nvl_seq_reset(nvl_model* m, int64_t seq_id);    /* NewKVCache on prefill (:63-66)              */
+int nvl_seq_close(nvl_model* m, int64_t seq_id);    /* ClearCache (:100-104)                       */
+int nvl_seq_close_all(nvl_model* m);                /* ClearAllCaches (:107-111)                   */
+int nvl_seq_len(nvl_model* m, int64_t seq_id);      /* cached tokens, or <0                        */
+
+/* ---- the hot path ---- */
+enum {
+    NVL_FWD_ALL_LOGITS = 1u   /* logits for every row (what generic_model.go:467-470 computes);
+                                 default is the last row of each sequence only (what every caller
+                                 keeps: GetLogitsForLastToken, generic_model.go:595-604)            */
+};
+
+/* Batched replacement of TransformerModel.ForwardWithCache (generic_model.go:276-480) +
+ * GetLogitsForLastToken (:595-604) + greedy argmax (cmd/ask/main.go:389-402) for n_seqs
+ * independent sequences.  `tokens` is the concatenation of each sequence's NEW tokens
+ * (seq_lens[i] of them, appended at position pos_offsets[i], which must equal the sequence's
+ * cached length).  logits_out (optional) receives [n_seqs, V] (or [sum(seq_lens), V] with
+ * NVL_FWD_ALL_LOGITS); argmax_out (optional) receives one greedy token per sequence. */
+int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* tokens,
+                const int32_t* seq_lens, const int32_t* pos_offsets, uint32_t flags,
+                float* logits_out, int32_t* argmax_out);
+
+/* Debug/parity: copy the residual stream after layer `layer` of the LAST nvl_forward call,
+ * [sum(seq_lens), H] fp32 (requires nvl_set_debug(m, 1) before the call). */
+int nvl_set_debug(nvl_model* m, int keep_hidden);
+int nvl_get_hidden(nvl_model* m, int layer, float* out, int64_t n_floats);
+/* Debug/parity: copy a sequence's cache for one layer as the reference lays it out,
+ * K and V each [nKV, T, hd] fp32 (kv_cache.go:5-6).  Returns T. */
+int nvl_get_kv(nvl_model* m, int64_t seq_id, int layer, float* k_out, float* v_out);
+
+/* ---- runner: ModelRunner.Run semantics (nanovllm/model_runner.go:9-16) ---- */
+/* Replaces TensorModelRunner.Run (tensor_model_runner.go:55-97) for a scheduler batch:
+ * token_ptrs[i]/token_lens[i] is Sequence.TokenIDs (full history).  is_prefill != 0 discards the
+ * sequence's cache and processes the whole history from position 0 (:63-66,75); otherwise only
+ * the last token at position len-1 (:78-80) — and a sequence the library holds no cache for (or
+ * a stale one) is transparently re-prefilled.  Returns greedy tokens in next_tokens[n_seqs]
+ * and, when logits_out != NULL, the last-row logits [n_seqs, V] for host-side sampling
+ * (tensor.SampleWithHistory stays in Go: sampling.go:33-102). */
+int nvl_runner_run(nvl_model* m, int n_seqs, const int64_t* seq_ids,
+                   const int32_t* const* token_ptrs, const int32_t* token_lens,
+                   int is_prefill, int32_t* next_tokens, float* logits_out);
+
+/* ---- measurement (the reference only has wall-clock prints: cmd/ask/main.go:196-198) ---- */
+typedef struct nvl_stats {
+    uint64_t forward_calls, prefill_tokens, decode_tokens;
+    double   prefill_ms, decode_ms;       /* device time of nvl_forward calls, by phase (HIP events) */
+    /* per-kernel-class device time, only when nvl_set_profile(m, 1): HIP events around each launch */
+    double   gemm_ms, gemm_flops;         /* all MFMA projection GEMMs (QKV, O, FFN, LM head)         */
+    uint64_t gemm_launches;
+    double   attn_ms, attn_flops;
+    uint64_t attn_launches;
+    double   other_ms;                    /* norms, RoPE/KV write, activation, embedding, argmax      */
+    uint64_t other_launches;
+    double   weight_bytes;                /* bytes of weights resident on the device                  */
+} nvl_stats;
+int nvl_set_profile(nvl_model* m, int per_kernel_events);
+int nvl_get_stats(nvl_model* m, nvl_stats* out);
+int nvl_reset_stats(nvl_model* m);
+
+const char* nvl_last_error(const nvl_model* m);   /* m may be NULL: last error of nvl_create */
+int nvl_abi_version(void);
+int nvl_device_count(void);                        /* number of visible HIP devices, 0 if none */
+
+/* ---- op-level entry points (host fp32 in / host fp32 out; used by the parity tests) ----
+ * Each runs the SAME device kernel the model path uses, on one op, in `precision`. */
+/* MatMul tensor.go:62-88: c[m,n] = a[m,k] x b[k,n] (b in the reference's [in,out] layout) */
+int nvl_op_matmul(int device, int precision, const float* a, const float* b, float* c,
+                  int m, int k, int n);
+/* LayerNorm tensor.go:193-250 (bias == NULL => RMSNorm) */
+int nvl_op_layernorm(int device, const float* x, const float* w, const float* bias, float eps,
+                     float* y, int rows, int hidden);
+/* Softmax tensor.go:128-160 over the last dim */
+int nvl_op_softmax(int device, const float* x, float* y, int rows, int cols);
+/* GELU tensor.go:181-190 / SiLU mamba2.go:360-367 */
+int nvl_op_gelu(int device, const float* x, float* y, int64_t n);
+int nvl_op_silu(int device, const float* x, float* y, int64_t n);
+/* ApplyRoPESingleTensor rope.go:153-205 on t [heads, seq, hd] in place */
+int nvl_op_rope(int device, float* t, int heads, int seq, int hd, int start_pos, double base,
+                int max_seq);
+/* GQA/MQA/MHA core on projected heads (attention.go:354-470, mqa.go:184-243):
+ * q [nH,S,hd], k/v [nKV,T,hd] (keys 0..T-1, the last S are the new tokens) -> out [nH,S,hd] */
+int nvl_op_attention(int device, int precision, const float* q, const float* k, const float* v,
+                     int nH, int nKV, int S, int T, int hd, float scale, float* out);
+/* FeedForward.Forward transformer.go:40-96 (w1 [H,2F] gate|up or [H,F]; w2 [F,H]) */
+int nvl_op_ffn(int device, int precision, const float* x, const float* w1, const float* b1,
+               const float* w2, const float* b2, int rows, int hidden, int ffn, int swiglu,
+               float* y);
+/* MoELayer.Forward moe.go:43-128 with separate experts (:167-226) */
+int nvl_op_moe(int device, int precision, const float* x, const float* router, const float* w_in,
+               const float* w_out, int rows, int hidden, int n_experts, int top_k, int inter,
+               float* y);
+/* argmax cmd/ask/main.go:389-402 (first strict maximum) */
+int nvl_op_argmax(int device, const float* x, int rows, int cols, int32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVLLM_H */

@@ -1,0 +1,129 @@
+"""ctypes binding of libnvllm_hip.so (include/nvllm.h).  There is no fallback: if the HIP library is
+missing this module raises, and if no GPU is visible every compute call returns NVL_ERR_NO_DEVICE."""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libnvllm_hip.so"
+HEADER = _PKG.parent / "include" / "nvllm.h"
+
+SLOTS = [
+    "tok_emb", "pos_emb", "lm_head", "final_norm_w", "final_norm_b",
+    "attn_norm_w", "attn_norm_b", "ffn_norm_w", "ffn_norm_b",
+    "wq", "wk", "wv", "wkv", "wo", "bq", "bk", "bv", "bo",
+    "w1", "b1", "w2", "b2", "router", "moe_in", "moe_out",
+]
+SLOT_ID = {n: i for i, n in enumerate(SLOTS)}
+ONE_D = {"final_norm_w", "final_norm_b", "attn_norm_w", "attn_norm_b", "ffn_norm_w", "ffn_norm_b",
+         "bq", "bk", "bv", "bo", "b1", "b2"}
+
+ATTN = {"mha": 0, "mqa": 1, "gqa": 2}
+NORM = {"layernorm": 0, "rmsnorm": 1}
+POS = {"learned": 0, "rope": 1, "nope": 2}
+ACT = {"gelu": 0, "swiglu": 1}
+BLOCK = {"sequential": 0, "parallel": 1}
+PRECISION = {"bf16": 0, "f32": 1}
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
+LAYOUT_IN_OUT, LAYOUT_OUT_IN = 0, 1
+FWD_ALL_LOGITS = 1
+
+STATUS = {0: "NVL_OK", -1: "NVL_ERR_INVALID", -2: "NVL_ERR_POSITION", -3: "NVL_ERR_UNKNOWN_SEQ",
+          -4: "NVL_ERR_NO_SLOT", -5: "NVL_ERR_OOM", -6: "NVL_ERR_HIP", -7: "NVL_ERR_STATE",
+          -8: "NVL_ERR_NO_DEVICE"}
+
+
+class NvlError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"nvllm: {STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class ModelConfigC(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_int32), ("hidden", C.c_int32), ("num_layers", C.c_int32),
+        ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32), ("head_dim", C.c_int32),
+        ("ffn_dim", C.c_int32), ("max_seq_len", C.c_int32),
+        ("attention_type", C.c_int32), ("norm_type", C.c_int32), ("position_type", C.c_int32),
+        ("activation_type", C.c_int32), ("block_style", C.c_int32),
+        ("rope_base", C.c_double), ("norm_eps", C.c_float), ("tied_embedding", C.c_int32),
+        ("use_moe", C.c_int32), ("num_experts", C.c_int32), ("num_experts_per_tok", C.c_int32),
+        ("embedding_multiplier", C.c_float), ("attention_multiplier", C.c_float),
+        ("residual_multiplier", C.c_float), ("logits_scaling", C.c_float),
+    ]
+
+
+class RuntimeOptsC(C.Structure):
+    _fields_ = [("device", C.c_int32), ("precision", C.c_int32), ("max_seqs", C.c_int32),
+                ("max_batch_tokens", C.c_int32), ("tp_rank", C.c_int32), ("tp_size", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
+
+
+class StatsC(C.Structure):
+    _fields_ = [("forward_calls", C.c_uint64), ("prefill_tokens", C.c_uint64), ("decode_tokens", C.c_uint64),
+                ("prefill_ms", C.c_double), ("decode_ms", C.c_double),
+                ("gemm_ms", C.c_double), ("gemm_flops", C.c_double), ("gemm_launches", C.c_uint64),
+                ("attn_ms", C.c_double), ("attn_flops", C.c_double), ("attn_launches", C.c_uint64),
+                ("other_ms", C.c_double), ("other_launches", C.c_uint64), ("weight_bytes", C.c_double)]
+
+
+def declared_symbols() -> list[str]:
+    """Every function include/nvllm.h declares (the drop-in surface)."""
+    text = HEADER.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nvl_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(str(LIB_PATH))
+    L.nvl_create.argtypes = [C.POINTER(ModelConfigC), C.POINTER(RuntimeOptsC), C.POINTER(vp)]
+    L.nvl_upload_tensor.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, i64, i64, C.c_int]
+    L.nvl_upload_gpt2_qkv.argtypes = [vp, C.c_int, vp, vp]
+    L.nvl_upload_falcon_qkv.argtypes = [vp, C.c_int, vp]
+    L.nvl_finalize.argtypes = [vp]
+    L.nvl_destroy.argtypes = [vp]
+    L.nvl_destroy.restype = None
+    for fn in ("nvl_seq_open", "nvl_seq_reset", "nvl_seq_close", "nvl_seq_len"):
+        getattr(L, fn).argtypes = [vp, i64]
+    L.nvl_seq_close_all.argtypes = [vp]
+    L.nvl_forward.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_uint32, vp, vp]
+    L.nvl_set_debug.argtypes = [vp, C.c_int]
+    L.nvl_get_hidden.argtypes = [vp, C.c_int, vp, i64]
+    L.nvl_get_kv.argtypes = [vp, i64, C.c_int, vp, vp]
+    L.nvl_runner_run.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp]
+    L.nvl_set_profile.argtypes = [vp, C.c_int]
+    L.nvl_get_stats.argtypes = [vp, C.POINTER(StatsC)]
+    L.nvl_reset_stats.argtypes = [vp]
+    L.nvl_last_error.argtypes = [vp]
+    L.nvl_last_error.restype = C.c_char_p
+    L.nvl_op_matmul.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int]
+    L.nvl_op_layernorm.argtypes = [C.c_int, vp, vp, vp, f32, vp, C.c_int, C.c_int]
+    L.nvl_op_softmax.argtypes = [C.c_int, vp, vp, C.c_int, C.c_int]
+    L.nvl_op_gelu.argtypes = [C.c_int, vp, vp, i64]
+    L.nvl_op_silu.argtypes = [C.c_int, vp, vp, i64]
+    L.nvl_op_rope.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
+    L.nvl_op_attention.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp]
+    L.nvl_op_ffn.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.nvl_op_moe.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.nvl_op_argmax.argtypes = [C.c_int, vp, C.c_int, C.c_int, vp]
+    _lib = L
+    return L
+
+
+def check(rc: int, handle=None):
+    if rc < 0:
+        msg = lib().nvl_last_error(handle)
+        raise NvlError(rc, msg.decode() if msg else "")
+    return rc

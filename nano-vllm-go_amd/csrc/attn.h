@@ -1,0 +1,231 @@
+// attn.h — causal attention over the per-sequence KV slabs.  Replaces, for all three
+// attention types, the reference's split/repeat/score/softmax/apply/merge loops:
+//   GQA  attention.go:217-274 (+ :300-470)      group = nH/nKV
+//   MHA  attention.go:34-64, :127-191           group = 1
+//   MQA  mqa.go:47-99, :163-267                 group = nH (all heads share one K/V tile)
+// No repeatKVHeads copy, no Concatenate re-copy, no [nH,S,T] score tensor.
+//
+// bf16 kernel (product path): flash-style, MFMA 16x16x32 bf16, fp32 online softmax.
+// One workgroup = 4 waves = 64 "query rows" of one (sequence, kv head); a query row is a
+// (position, head-in-group) pair, position-major, so every head of a GQA/MQA group reuses the
+// same K/V tile from LDS.  Per wave 16 rows.  The products are issued transposed:
+//     S^T[key, q] = K[key, :] · Q[q, :]^T          (A = K tile rows,   B = Q rows, from registers)
+//     O^T[d,  q] += V^T[d, key] · P^T[key, q]      (A = V^T tile rows, B = P^T straight from the
+//                                                   S^T accumulators — no LDS, no shuffles)
+// so the softmax row (fixed q) lives on one lane column: the max/sum need two xor-shuffles, and the
+// O rescale is lane-local.  The V cache is kept TRANSPOSED in HBM ([hd][T]) so the V^T tile is a
+// coalesced load and its fragments are 8-byte LDS reads.
+//
+// f32 kernel (parity mode): one workgroup per (query position, head); scores in LDS; plain fp32.
+#pragma once
+#include "common.h"
+
+namespace nvl {
+
+struct AttnArgs {
+    const void* q;        // [tokens][q_stride]; head h at column h*HD (bf16 or f32)
+    int q_stride;
+    void* out;            // [tokens][out_stride]; head h at column h*HD
+    int out_stride;
+    const void* kcache;   // layer base; (slot, kvh) at slot*slot_stride + kvh*Tmax*HD; [Tmax][HD]
+    const void* vcache;   // bf16: V^T [HD][Tmax]; f32: [Tmax][HD]
+    int64_t slot_stride;  // elements
+    int Tmax;
+    const int32_t* seq_tok_start;
+    const int32_t* seq_len;
+    const int32_t* seq_pos;
+    const int32_t* seq_slot;
+    int nH, nKV, group;
+    float scale;
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
+    constexpr int KROW = HD + 8;       // bf16 elements per K tile row (padded: 144 B for HD=64)
+    constexpr int VROW = 64 + 8;       // bf16 elements per V^T tile row
+    constexpr int KS = HD / 32;        // k-steps of the QK^T product
+    constexpr int DT = HD / 16;        // 16-row d tiles of O^T
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * KROW];
+    __shared__ __attribute__((aligned(16))) bf16_t Vts[HD * VROW];
+
+    const int seq = blockIdx.z, kvh = blockIdx.y, qt = blockIdx.x;
+    const int S = p.seq_len[seq];
+    const int R = S * p.group;                 // query rows of this (seq, kv head)
+    if (qt * 64 >= R) return;
+    const int tok0 = p.seq_tok_start[seq], pos0 = p.seq_pos[seq], slot = p.seq_slot[seq];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fq = lane & 15, fg = lane >> 4;
+
+    // ---- this lane's query row ----
+    int row = qt * 64 + wave * 16 + fq;
+    const bool row_ok = row < R;
+    if (!row_ok) row = qt * 64;                // clamp to a valid row; result discarded
+    const int s_idx = row / p.group, hg = row - s_idx * p.group;
+    const int head = kvh * p.group + hg;
+    const int limit = pos0 + s_idx;            // last key this row may attend to (causal)
+    const bf16_t* qp = (const bf16_t*)p.q + (int64_t)(tok0 + s_idx) * p.q_stride + head * HD;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) qf[ks] = *(const bf16x8*)(qp + ks * 32 + fg * 8);
+
+    // last key any row of this workgroup needs
+    int last_row = qt * 64 + 63;
+    if (last_row > R - 1) last_row = R - 1;
+    const int kmax = pos0 + last_row / p.group;
+    const int n_kt = kmax / 64 + 1;
+
+    const bf16_t* kbase = (const bf16_t*)p.kcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
+    const bf16_t* vbase = (const bf16_t*)p.vcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
+
+    f32x4 o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; d++) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int kt = 0; kt < n_kt; kt++) {
+        __syncthreads();
+        // ---- stage K tile [64 keys][HD] and V^T tile [HD][64 keys] (register staged) ----
+        {
+            constexpr int KCH = HD / 8;              // 16-B chunks per K row
+#pragma unroll
+            for (int c = tid; c < 64 * KCH; c += 256) {
+                const int r = c / KCH, cc = c % KCH;
+                const bf16x8 v = *(const bf16x8*)(kbase + (int64_t)(kt * 64 + r) * HD + cc * 8);
+                *(bf16x8*)(Ks + r * KROW + cc * 8) = v;
+            }
+#pragma unroll
+            for (int c = tid; c < HD * 8; c += 256) {
+                const int r = c >> 3, cc = c & 7;
+                const bf16x8 v = *(const bf16x8*)(vbase + (int64_t)r * p.Tmax + kt * 64 + cc * 8);
+                *(bf16x8*)(Vts + r * VROW + cc * 8) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T = K · Q^T : 4 sub-tiles of 16 keys ----
+        f32x4 s[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const bf16x8 kf = *(const bf16x8*)(Ks + (t * 16 + fq) * KROW + ks * 32 + fg * 8);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+            }
+        }
+        // lane holds S^T[key = kt*64 + 16t + 4fg + r][q = fq]
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int key = kt * 64 + t * 16 + fg * 4 + r;
+                float v = s[t][r] * p.scale;
+                v = (key <= limit) ? v : -INFINITY;      // reference: -1e10 then exp() == 0 exactly
+                s[t][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);          // finite: key 0 is always visible in tile 0
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float pv = __expf(s[t][r] - m_new);
+                s[t][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < DT; d++) o[d] *= alpha;
+
+        // ---- O^T += V^T · P^T : k index permuted identically on both operands ----
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            bf16x8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                pf[r] = (bf16_t)s[2 * u][r];          // keys 32u + 4fg + r
+                pf[4 + r] = (bf16_t)s[2 * u + 1][r];  // keys 32u + 16 + 4fg + r
+            }
+#pragma unroll
+            for (int d = 0; d < DT; d++) {
+                const bf16_t* vr = Vts + (d * 16 + fq) * VROW + u * 32 + fg * 4;
+                const bf16x4 lo = *(const bf16x4*)(vr);
+                const bf16x4 hi = *(const bf16x4*)(vr + 16);
+                bf16x8 vf;
+#pragma unroll
+                for (int r = 0; r < 4; r++) { vf[r] = lo[r]; vf[4 + r] = hi[r]; }
+                o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[d], 0, 0, 0);
+            }
+        }
+    }
+
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (!row_ok) return;
+    const float inv = 1.0f / l_run;
+    bf16_t* op = (bf16_t*)p.out + (int64_t)(tok0 + s_idx) * p.out_stride + head * HD;
+#pragma unroll
+    for (int d = 0; d < DT; d++) {
+        bf16x4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; r++) ov[r] = (bf16_t)(o[d][r] * inv);
+        *(bf16x4*)(op + d * 16 + fg * 4) = ov;    // O[q][d = 16d + 4fg + r]
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 parity kernel: block = (query position, head), 256 threads, T <= 8192
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p, int HD) {
+    extern __shared__ float sc[];                 // [T_max_needed] scores then probs
+    __shared__ float red[8];
+    const int seq = blockIdx.z, head = blockIdx.y, s_idx = blockIdx.x;
+    if (s_idx >= p.seq_len[seq]) return;
+    const int tid = threadIdx.x;
+    const int kvh = head / p.group;
+    const int tok = p.seq_tok_start[seq] + s_idx;
+    const int T = p.seq_pos[seq] + s_idx + 1;     // keys 0..limit
+    const int slot = p.seq_slot[seq];
+    const float* q = (const float*)p.q + (int64_t)tok * p.q_stride + head * HD;
+    const float* kb = (const float*)p.kcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
+    const float* vb = (const float*)p.vcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
+
+    float lmax = -INFINITY;
+    for (int j = tid; j < T; j += 256) {
+        const float* kr = kb + (int64_t)j * HD;
+        float sum = 0.f;
+        for (int d = 0; d < HD; d++) sum = fmaf(q[d], kr[d], sum);
+        sum *= p.scale;
+        sc[j] = sum;
+        lmax = fmaxf(lmax, sum);
+    }
+    lmax = wave_max(lmax);
+    if ((tid & 63) == 0) red[tid >> 6] = lmax;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float lsum = 0.f;
+    for (int j = tid; j < T; j += 256) {
+        const float e = expf(sc[j] - mx);
+        sc[j] = e;
+        lsum += e;
+    }
+    lsum = wave_sum(lsum);
+    __syncthreads();
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = lsum;
+    __syncthreads();
+    const float tot = red[4] + red[5] + red[6] + red[7];
+    float* op = (float*)p.out + (int64_t)tok * p.out_stride + head * HD;
+    for (int d = tid; d < HD; d += 256) {
+        float acc = 0.f;
+        for (int j = 0; j < T; j++) acc = fmaf(sc[j] / tot, vb[(int64_t)j * HD + d], acc);
+        op[d] = acc;
+    }
+}
+
+}  // namespace nvl

@@ -1,0 +1,62 @@
+// common.h — shared device/host helpers for libnvllm_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+namespace nvl {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define NVL_WAVE 64
+
+// ---- bf16 conversions -------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }  // RNE, NaN stays NaN (v_cvt_pk_bf16_f32)
+
+template <typename T> struct ActIO;
+template <> struct ActIO<float> {
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct ActIO<bf16_t> {
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return (float)*p; }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = (bf16_t)v; }
+};
+
+// ---- wave reductions (64 lanes) ----------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- host error plumbing -------------------------------------------------------
+struct HipError {
+    hipError_t code;
+    const char* what;
+    const char* file;
+    int line;
+};
+
+#define NVL_HIP(expr)                                                                 \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) throw ::nvl::HipError{_e, #expr, __FILE__, __LINE__};   \
+    } while (0)
+
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace nvl

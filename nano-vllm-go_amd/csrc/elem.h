@@ -1,0 +1,345 @@
+// elem.h — wavefront-reduction / element kernels of the forward path: embedding gather,
+// RMSNorm/LayerNorm, RoPE + KV append, activations, softmax, MoE routing, argmax, and the
+// load-time layout converters.  All HBM-bound; fp32 math; one 64-lane wave per row where a
+// reduction is needed.  ActT is the activation storage type handed to the next GEMM
+// (bf16 in the product path, float in the fp32 parity mode).
+#pragma once
+#include "common.h"
+
+namespace nvl {
+
+// ---------------------------------------------------------------------------------------
+// embedWithOffset (generic_model.go:567-592) + EmbeddingMultiplier (:298-302)
+// ---------------------------------------------------------------------------------------
+template <typename WT>
+__global__ void embed_kernel(const int32_t* __restrict__ tokens, const int32_t* __restrict__ tok_pos,
+                             const WT* __restrict__ emb, const WT* __restrict__ pos_emb,
+                             int max_seq, float mult, float* __restrict__ x, int H) {
+    const int t = blockIdx.x;
+    const int tok = tokens[t];
+    const WT* er = emb + (int64_t)tok * H;
+    const int pos = tok_pos[t];
+    const WT* pr = (pos_emb && pos < max_seq) ? pos_emb + (int64_t)pos * H : nullptr;
+    float* xr = x + (int64_t)t * H;
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+        float v = (float)er[j];
+        if (pr) v += (float)pr[j];
+        if (mult != 0.f) v *= mult;
+        xr[j] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm / RMSNorm (tensor.go:193-250): one wave per row, 4 rows per 256-thread block.
+// rows_idx (optional) gathers input rows (final norm on the last row of each sequence only).
+// ---------------------------------------------------------------------------------------
+template <typename ActT>
+__global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x,
+                                                   const int32_t* __restrict__ rows_idx,
+                                                   const float* __restrict__ w,
+                                                   const float* __restrict__ b, float eps,
+                                                   ActT* __restrict__ y, int rows, int H) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int src = rows_idx ? rows_idx[r] : r;
+    const float* xr = x + (int64_t)src * H;
+    ActT* yr = y + (int64_t)r * H;
+    const int H4 = H >> 2;  // H % 4 == 0 for every supported model
+    if (b == nullptr) {
+        float ss = 0.f;
+        for (int j = lane; j < H4; j += 64) {
+            const f32x4 v = *(const f32x4*)(xr + j * 4);
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+        ss = wave_sum(ss);
+        const float rms = sqrtf(ss / (float)H + eps);
+        for (int j = lane; j < H4; j += 64) {
+            const f32x4 v = *(const f32x4*)(xr + j * 4);
+            const f32x4 ww = *(const f32x4*)(w + j * 4);
+#pragma unroll
+            for (int k = 0; k < 4; k++) ActIO<ActT>::st(yr + j * 4 + k, (v[k] / rms) * ww[k]);
+        }
+    } else {
+        float s = 0.f;
+        for (int j = lane; j < H4; j += 64) {
+            const f32x4 v = *(const f32x4*)(xr + j * 4);
+            s += v[0] + v[1] + v[2] + v[3];
+        }
+        const float mean = wave_sum(s) / (float)H;
+        float vs = 0.f;
+        for (int j = lane; j < H4; j += 64) {
+            const f32x4 v = *(const f32x4*)(xr + j * 4);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const float d = v[k] - mean; vs += d * d; }
+        }
+        const float var = wave_sum(vs) / (float)H;
+        const float sd = sqrtf(var + eps);
+        for (int j = lane; j < H4; j += 64) {
+            const f32x4 v = *(const f32x4*)(xr + j * 4);
+            const f32x4 ww = *(const f32x4*)(w + j * 4);
+            const f32x4 bb = *(const f32x4*)(b + j * 4);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                ActIO<ActT>::st(yr + j * 4 + k, ((v[k] - mean) / sd) * ww[k] + bb[k]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// RoPE (rope.go:153-205) on Q and K as they leave the fused QKV GEMM, plus the KV append that
+// replaces Concatenate (tensor.go:283-321): K -> slab[pos][hd], V -> slab (bf16: V^T [hd][pos]).
+// qkv is fp32 [tokens][(nH+2nKV)*HD] = [Q heads | K heads | V heads].
+// grid = (tokens, nH + 2*nKV), block = HD/2 threads... one thread per rotation pair.
+// ---------------------------------------------------------------------------------------
+template <typename ActT, bool VT>
+__global__ void rope_kv_kernel(const float* __restrict__ qkv, int qkv_stride,
+                               const int32_t* __restrict__ tok_pos, const int32_t* __restrict__ tok_slot,
+                               const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                               ActT* __restrict__ q_out, int q_stride,
+                               ActT* __restrict__ kcache, ActT* __restrict__ vcache,
+                               int64_t slot_stride, int Tmax, int nH, int nKV, int HD) {
+    const int t = blockIdx.x, h = blockIdx.y;
+    const int pos = tok_pos[t], slot = tok_slot[t];
+    const int half = HD >> 1;
+    const float* src = qkv + (int64_t)t * qkv_stride + (int64_t)h * HD;
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        float x1 = src[i], x2 = src[i + half];
+        float y1 = x1, y2 = x2;
+        if (h < nH + nKV && cos_t) {
+            const float c1 = cos_t[(int64_t)pos * HD + i], s1 = sin_t[(int64_t)pos * HD + i];
+            const float c2 = cos_t[(int64_t)pos * HD + half + i], s2 = sin_t[(int64_t)pos * HD + half + i];
+            y1 = x1 * c1 + (-x2) * s1;   // rope.go:196-202: x*cos + rotate_half(x)*sin
+            y2 = x2 * c2 + x1 * s2;
+        }
+        if (h < nH) {
+            ActT* d = q_out + (int64_t)t * q_stride + (int64_t)h * HD;
+            ActIO<ActT>::st(d + i, y1);
+            ActIO<ActT>::st(d + i + half, y2);
+        } else if (h < nH + nKV) {
+            const int kvh = h - nH;
+            ActT* d = kcache + (int64_t)slot * slot_stride + ((int64_t)kvh * Tmax + pos) * HD;
+            ActIO<ActT>::st(d + i, y1);
+            ActIO<ActT>::st(d + i + half, y2);
+        } else {
+            const int kvh = h - nH - nKV;
+            if (VT) {
+                ActT* d = vcache + (int64_t)slot * slot_stride + (int64_t)kvh * Tmax * HD;
+                ActIO<ActT>::st(d + (int64_t)i * Tmax + pos, y1);
+                ActIO<ActT>::st(d + (int64_t)(i + half) * Tmax + pos, y2);
+            } else {
+                ActT* d = vcache + (int64_t)slot * slot_stride + ((int64_t)kvh * Tmax + pos) * HD;
+                ActIO<ActT>::st(d + i, y1);
+                ActIO<ActT>::st(d + i + half, y2);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// un-fused activations for the fp32 parity mode and the op-level entry points
+// ---------------------------------------------------------------------------------------
+// h [rows][2F] = [gate | up] -> y [rows][F] = silu(gate)*up   (transformer.go:50-66)
+template <typename ActT>
+__global__ void swiglu_kernel(const float* __restrict__ h, ActT* __restrict__ y, int64_t rows, int F) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * F) return;
+    const int64_t r = i / F; const int f = (int)(i - r * F);
+    const float g = h[r * 2 * F + f], u = h[r * 2 * F + F + f];
+    ActIO<ActT>::st(y + i, (g / (1.0f + expf(-g))) * u);
+}
+__global__ void gelu_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    const float inner = 0.7978845608028654f * (v + 0.044715f * (v * v * v));
+    y[i] = 0.5f * v * (1.0f + tanhf(inner));
+}
+__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    y[i] = v / (1.0f + expf(-v));
+}
+
+// Softmax over the last dim (tensor.go:128-160): one wave per row.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x,
+                                                           float* __restrict__ y, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* xr = x + (int64_t)r * cols;
+    float* yr = y + (int64_t)r * cols;
+    float mx = -INFINITY;
+    for (int j = lane; j < cols; j += 64) mx = fmaxf(mx, xr[j]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int j = lane; j < cols; j += 64) { const float e = expf(xr[j] - mx); yr[j] = e; s += e; }
+    s = wave_sum(s);
+    for (int j = lane; j < cols; j += 64) yr[j] = yr[j] / s;
+}
+
+// ---------------------------------------------------------------------------------------
+// greedy argmax (cmd/ask/main.go:389-402: first strict maximum) + LogitsScaling divide
+// (generic_model.go:473-477).  One block per row; logits modified in place when scale != 0.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void argmax_kernel(float* __restrict__ logits, int ld, int V,
+                                                     float logits_scaling, int32_t* __restrict__ out) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    float* row = logits + (int64_t)blockIdx.x * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = threadIdx.x; j < V; j += 256) {
+        float v = row[j];
+        if (logits_scaling != 0.f) { v = v / logits_scaling; row[j] = v; }
+        if (v > best) { best = v; bi = j; }      // strict >, ascending j => first max per thread
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++)
+            if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+        if (bi == 0x7fffffff) bi = 0;   // all -inf / NaN: reference returns index 0
+        out[blockIdx.x] = bi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// MoE routing (moe.go:63-92): softmax over E, top-k by descending prob (ties: lower expert
+// index first — the reference's sort.Slice is unstable, this is the documented tie rule),
+// weights renormalised over the chosen k.  One wave per token, E <= 64.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void moe_route_kernel(const float* __restrict__ router_logits, int ld,
+                                                        int rows, int E, int top_k,
+                                                        int32_t* __restrict__ expert_ids,   // [rows][k]
+                                                        float* __restrict__ expert_w) {     // [rows][k]
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float v = (lane < E) ? router_logits[(int64_t)r * ld + lane] : -INFINITY;
+    const float mx = wave_max(v);
+    const float e = (lane < E) ? expf(v - mx) : 0.f;
+    const float s = wave_sum(e);
+    float prob = (lane < E) ? e / s : -1.f;
+    float wsum = 0.f;
+    float my_w = 0.f;
+    int my_e = 0;
+    for (int k = 0; k < top_k; k++) {
+        float bv = prob;
+        int bi = lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        wsum += bv;                       // moe.go:89-92: fp32 sum in rank order
+        if (lane == k) { my_w = bv; my_e = bi; }
+        if (lane == bi) prob = -1.f;      // remove the winner
+    }
+    if (lane < top_k) {
+        expert_ids[(int64_t)r * top_k + lane] = my_e;
+        expert_w[(int64_t)r * top_k + lane] = my_w / wsum;   // moe.go:103
+    }
+}
+
+// out[t] (+)= resid_mult * sum_rank w[t][rank] * eo[slot_of(t,rank)]   in rank order
+// (moe.go:117-119 accumulates in expert-rank order; generic_model.go:383-389 adds the residual)
+__global__ void moe_combine_kernel(const float* __restrict__ eo, const int32_t* __restrict__ slot_of,
+                                   const float* __restrict__ w, int top_k, float resid_mult,
+                                   float* __restrict__ x, int H, int accumulate_into_x) {
+    const int t = blockIdx.x;
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+        float acc = 0.f;
+        for (int k = 0; k < top_k; k++) {
+            const int sl = slot_of[(int64_t)t * top_k + k];
+            acc += w[(int64_t)t * top_k + k] * eo[(int64_t)sl * H + j];
+        }
+        float* xp = x + (int64_t)t * H + j;
+        if (accumulate_into_x) *xp = *xp + (resid_mult != 0.f ? resid_mult * acc : acc);
+        else *xp = acc;
+    }
+}
+
+// counting sort of (token, rank) pairs by expert: single block; rows*k up to a few 100k.
+// seg_start[e]..seg_start[e+1] rows of `perm_token` belong to expert e; slot_of[t*k+rank] = sorted row.
+__global__ __launch_bounds__(1024) void moe_sort_kernel(const int32_t* __restrict__ expert_ids, int n_pairs,
+                                                        int E, int top_k, int32_t* __restrict__ seg_start,
+                                                        int32_t* __restrict__ perm_token,
+                                                        int32_t* __restrict__ slot_of) {
+    __shared__ int cnt[64];
+    __shared__ int start[65];
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_pairs; i += blockDim.x) atomicAdd(&cnt[expert_ids[i]], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0;
+        for (int e = 0; e < E; e++) { start[e] = a; a += cnt[e]; }
+        start[E] = a;
+        for (int e = 0; e <= E; e++) seg_start[e] = start[e];
+    }
+    __syncthreads();
+    // deterministic placement: expert e's rows ordered by pair index (token-major)
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        int pos = start[e];
+        for (int i = 0; i < n_pairs; i++)
+            if (expert_ids[i] == e) { perm_token[pos] = i / top_k; slot_of[i] = pos; pos++; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// load-time converters (generic_loader.go:642-663 dtype expansion, tensor.go:112-125 Transpose)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float ld_as_f32(const void* p, int dtype, int64_t i) {
+    if (dtype == 0) return ((const float*)p)[i];
+    if (dtype == 1) return (float)((const bf16_t*)p)[i];
+    return (float)((const _Float16*)p)[i];
+}
+// dst[n][k] (n < N, k < K) from src in IN_OUT ([K][N]) or OUT_IN ([N][K]) order
+template <typename DT>
+__global__ void convert_2d_kernel(const void* __restrict__ src, int dtype, int transpose_in,
+                                  DT* __restrict__ dst, int64_t N, int64_t K) {
+    __shared__ float tile[32][33];
+    const int64_t n0 = (int64_t)blockIdx.y * 32, k0 = (int64_t)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
+    if (transpose_in) {
+        for (int r = ty; r < 32; r += 8) {
+            const int64_t k = k0 + r, n = n0 + tx;
+            tile[r][tx] = (k < K && n < N) ? ld_as_f32(src, dtype, k * N + n) : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int64_t n = n0 + r, k = k0 + tx;
+            if (n < N && k < K) dst[n * K + k] = (DT)tile[tx][r];
+        }
+    } else {
+        for (int r = ty; r < 32; r += 8) {
+            const int64_t n = n0 + r, k = k0 + tx;
+            if (n < N && k < K) dst[n * K + k] = (DT)ld_as_f32(src, dtype, n * K + k);
+        }
+    }
+}
+__global__ void convert_1d_kernel(const void* __restrict__ src, int dtype, float* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = ld_as_f32(src, dtype, i);
+}
+// dst row r (of K elements) = src row idx[r], or zeros when idx[r] < 0
+template <typename DT>
+__global__ void gather_rows_kernel(const DT* __restrict__ src, const int32_t* __restrict__ idx,
+                                   DT* __restrict__ dst, int64_t K) {
+    const int64_t r = blockIdx.x;
+    const int s = idx[r];
+    for (int64_t k = threadIdx.x; k < K; k += blockDim.x)
+        dst[r * K + k] = (s >= 0) ? src[(int64_t)s * K + k] : (DT)0.f;
+}
+
+}  // namespace nvl

@@ -1,0 +1,90 @@
+// model.h — host-side state of one nvl_model handle (device weights in kernel layout, KV slabs,
+// workspaces, the HIP stream) and the kernel launch helpers shared by nvllm.hip and ops.hip.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/nvllm.h"
+#include "attn.h"
+#include "common.h"
+#include "elem.h"
+#include "gemm.h"
+
+namespace nvl {
+
+struct DevTensor {
+    void* p = nullptr;      // canonical device copy: 2-D [rows_pad][cols] in weight dtype, 1-D fp32
+    int64_t rows = 0, cols = 0, rows_pad = 0;
+    bool present() const { return p != nullptr; }
+};
+
+struct LayerW {
+    DevTensor t[NVL_T_COUNT];
+    // frozen by finalize()
+    void* w_qkv = nullptr; int n_qkv = 0; float* b_qkv = nullptr;
+    void* w1 = nullptr; int n1 = 0;      // fused rows (2F for SwiGLU, F for GELU)
+    void* moe_in = nullptr;              // [E][2I (interleaved in bf16 mode)][H]
+};
+
+enum KClass { KC_GEMM = 0, KC_ATTN = 1, KC_OTHER = 2 };
+
+struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+
+}  // namespace nvl
+
+struct nvl_model {
+    nvl_model_config cfg{};
+    nvl_runtime_opts opts{};
+    bool f32 = false;            // NVL_PRECISION_F32
+    bool finalized = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // derived
+    int H = 0, nH = 0, nKV = 0, hd = 0, F = 0, V = 0, Vpad = 0, L = 0, group = 1;
+    int n_qkv = 0, Tmax = 0;
+    float attn_scale = 0.f, resid_alpha = 1.f;
+    size_t wsize = 2;            // bytes per weight/activation element
+
+    nvl::DevTensor g[NVL_T_COUNT];       // model-level tensors
+    std::vector<nvl::LayerW> layers;
+    void* lm_head = nullptr;             // [Vpad][H] (aliases tok_emb when tied)
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+
+    // KV slabs
+    void *kcache = nullptr, *vcache = nullptr;
+    int64_t slot_stride = 0, layer_stride = 0;    // elements
+    std::map<int64_t, int> seq_slot;
+    std::vector<int> free_slots;
+    std::vector<int> slot_len;
+
+    // workspaces
+    float* x = nullptr;          // residual stream fp32 [Mmax][H]
+    void* xn = nullptr;          // normed activations (ActT)
+    float* qkv = nullptr;        // fp32 [Mmax][n_qkv]
+    void* q = nullptr;           // ActT [Mmax][nH*hd]
+    void* attn_out = nullptr;    // ActT [Mmax][nH*hd]
+    void* hbuf = nullptr;        // ActT [Mmax][F]   (MoE: [Mmax*k][I])
+    float* h2 = nullptr;         // fp32 [Mmax][2F]  (f32 mode un-fused gate|up; MoE f32 too)
+    void* xn_last = nullptr;     // ActT [rows][H]
+    float* logits = nullptr;     // fp32 [logit_rows][Vpad]
+    int64_t logit_rows = 0;
+    int32_t* argmax_dev = nullptr;
+    // MoE
+    float* router_logits = nullptr;   // [Mmax][128]
+    int32_t* expert_ids = nullptr; float* expert_w = nullptr;
+    int32_t *seg_start = nullptr, *perm_token = nullptr, *slot_of = nullptr;
+    float* moe_eo = nullptr;          // [Mmax*k][H]
+    // per-call metadata (one pinned host block mirrored on the device)
+    int32_t* meta_host = nullptr; int32_t* meta_dev = nullptr; int64_t meta_ints = 0;
+    // debug
+    bool keep_hidden = false; float* hidden = nullptr; int64_t hidden_tokens = 0; int hidden_last_M = 0;
+    // stats
+    nvl_stats stats{};
+    bool profile = false;
+    std::vector<nvl::ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};

@@ -1,0 +1,1013 @@
+// nvllm.hip — the C ABI of include/nvllm.h: model lifecycle, weight upload into kernel layouts,
+// KV slot management, and the batched prefill/decode forward that replaces
+// TransformerModel.ForwardWithCache (purego/tensor/generic_model.go:276-480).
+//
+// There is NO CPU fallback in this library: every entry point that computes needs a gfx950
+// device and fails with NVL_ERR_NO_DEVICE / NVL_ERR_HIP otherwise.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "model.h"
+
+using namespace nvl;
+
+static thread_local std::string g_create_err;
+
+namespace {
+
+int fail(nvl_model* m, int code, const std::string& msg) {
+    if (m) m->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define NVL_TRY(m) try {
+#define NVL_CATCH(m)                                                                     \
+    } catch (const HipError& e) {                                                        \
+        char buf[512];                                                                   \
+        snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e.code,         \
+                 hipGetErrorString(e.code), e.file, e.line, e.what);                     \
+        return fail(m, e.code == hipErrorOutOfMemory ? NVL_ERR_OOM : NVL_ERR_HIP, buf);  \
+    } catch (const std::exception& e) {                                                  \
+        return fail(m, NVL_ERR_INVALID, e.what());                                       \
+    }
+
+template <typename T>
+T* dmalloc(int64_t n) {
+    void* p = nullptr;
+    if (n <= 0) n = 1;
+    NVL_HIP(hipMalloc(&p, (size_t)n * sizeof(T)));
+    return (T*)p;
+}
+void* dmalloc_bytes(int64_t n) {
+    void* p = nullptr;
+    if (n <= 0) n = 16;
+    NVL_HIP(hipMalloc(&p, (size_t)n));
+    return p;
+}
+void dfree(void* p) { if (p) (void)hipFree(p); }
+
+bool is_1d(int kind) {
+    switch (kind) {
+        case NVL_T_FINAL_NORM_W: case NVL_T_FINAL_NORM_B: case NVL_T_ATTN_NORM_W: case NVL_T_ATTN_NORM_B:
+        case NVL_T_FFN_NORM_W: case NVL_T_FFN_NORM_B: case NVL_T_BQ: case NVL_T_BK: case NVL_T_BV:
+        case NVL_T_BO: case NVL_T_B1: case NVL_T_B2: return true;
+        default: return false;
+    }
+}
+bool is_global(int kind) { return kind < NVL_T_ATTN_NORM_W; }
+
+DevTensor* tensor_slot(nvl_model* m, int kind, int layer) {
+    if (kind < 0 || kind >= NVL_T_COUNT) return nullptr;
+    if (is_global(kind)) return &m->g[kind];
+    if (layer < 0 || layer >= m->L) return nullptr;
+    return &m->layers[layer].t[kind];
+}
+
+// ---- profiling helpers --------------------------------------------------------------------
+hipEvent_t get_event(nvl_model* m) {
+    if (!m->ev_pool.empty()) { hipEvent_t e = m->ev_pool.back(); m->ev_pool.pop_back(); return e; }
+    hipEvent_t e; NVL_HIP(hipEventCreate(&e)); return e;
+}
+struct KScope {   // brackets ONE kernel launch with HIP events on the model's stream
+    nvl_model* m; int cls; double flops; hipEvent_t a = nullptr, b = nullptr;
+    KScope(nvl_model* m_, int cls_, double flops_ = 0) : m(m_), cls(cls_), flops(flops_) {
+        if (m->profile) { a = get_event(m); b = get_event(m); NVL_HIP(hipEventRecord(a, m->stream)); }
+    }
+    ~KScope() {
+        if (m->profile && a) { (void)hipEventRecord(b, m->stream); m->prof.push_back({a, b, cls, flops}); }
+    }
+};
+void drain_profile(nvl_model* m) {
+    for (auto& r : m->prof) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        if (r.cls == KC_GEMM) { m->stats.gemm_ms += ms; m->stats.gemm_flops += r.flops; m->stats.gemm_launches++; }
+        else if (r.cls == KC_ATTN) { m->stats.attn_ms += ms; m->stats.attn_flops += r.flops; m->stats.attn_launches++; }
+        else { m->stats.other_ms += ms; m->stats.other_launches++; }
+        m->ev_pool.push_back(r.a); m->ev_pool.push_back(r.b);
+    }
+    m->prof.clear();
+}
+
+// ---- GEMM dispatch ---------------------------------------------------------------------------
+// out_f32: output element type of STORE (fp32 vs activation type)
+void gemm(nvl_model* m, int epi, bool out_f32, GemmArgs a) {
+    KScope ks(m, KC_GEMM, 2.0 * (double)a.M * (double)a.N * (double)a.K);
+    hipStream_t st = m->stream;
+    if (m->f32) {
+        switch (epi) {
+            case EPI_STORE: launch_gemm_f32<EPI_STORE, float>(st, a); break;
+            case EPI_RESID: launch_gemm_f32<EPI_RESID, float>(st, a); break;
+            case EPI_GELU:  launch_gemm_f32<EPI_GELU, float>(st, a); break;
+            default: throw std::runtime_error("gemm: epilogue not available in f32 mode");
+        }
+    } else {
+        switch (epi) {
+            case EPI_STORE:
+                if (out_f32) launch_gemm_bf16<EPI_STORE, float>(st, a);
+                else launch_gemm_bf16<EPI_STORE, bf16_t>(st, a);
+                break;
+            case EPI_RESID:  launch_gemm_bf16<EPI_RESID, float>(st, a); break;
+            case EPI_SWIGLU: launch_gemm_bf16<EPI_SWIGLU, bf16_t>(st, a); break;
+            case EPI_GELU:   launch_gemm_bf16<EPI_GELU, bf16_t>(st, a); break;
+            default: throw std::runtime_error("gemm: bad epilogue");
+        }
+    }
+    NVL_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+// =================================================================================================
+// lifecycle
+// =================================================================================================
+extern "C" int nvl_abi_version(void) { return NVL_ABI_VERSION; }
+
+extern "C" int nvl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char* nvl_last_error(const nvl_model* m) { return m ? m->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int nvl_create(const nvl_model_config* cfg, const nvl_runtime_opts* opts, nvl_model** out) {
+    if (!cfg || !opts || !out) return fail(nullptr, NVL_ERR_INVALID, "nvl_create: null argument");
+    *out = nullptr;
+    if (nvl_device_count() <= opts->device)
+        return fail(nullptr, NVL_ERR_NO_DEVICE,
+                    "nvl_create: no HIP device (this library has no CPU fallback)");
+    const nvl_model_config& c = *cfg;
+    if (c.hidden <= 0 || c.num_layers <= 0 || c.num_heads <= 0 || c.head_dim <= 0 || c.vocab_size <= 0 ||
+        c.max_seq_len <= 0)
+        return fail(nullptr, NVL_ERR_INVALID, "nvl_create: non-positive model dimension");
+    if (c.head_dim != 64 && c.head_dim != 128)
+        return fail(nullptr, NVL_ERR_INVALID, "nvl_create: head_dim must be 64 or 128");
+    if (c.hidden % 64 != 0 || (c.ffn_dim % 64) != 0)
+        return fail(nullptr, NVL_ERR_INVALID, "nvl_create: hidden and ffn_dim must be multiples of 64");
+    if (opts->tp_size > 1)
+        return fail(nullptr, NVL_ERR_INVALID, "nvl_create: tensor parallel shards are not implemented yet");
+    nvl_model* m = new nvl_model();
+    NVL_TRY(m)
+    m->cfg = c; m->opts = *opts;
+    m->f32 = (opts->precision == NVL_PRECISION_F32);
+    m->wsize = m->f32 ? 4 : 2;
+    m->device = opts->device;
+    NVL_HIP(hipSetDevice(m->device));
+    NVL_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    NVL_HIP(hipEventCreate(&m->ev0));
+    NVL_HIP(hipEventCreate(&m->ev1));
+    m->H = c.hidden; m->nH = c.num_heads; m->hd = c.head_dim; m->F = c.ffn_dim; m->V = c.vocab_size;
+    m->L = c.num_layers;
+    m->nKV = c.attention_type == NVL_ATTN_MHA ? c.num_heads : (c.attention_type == NVL_ATTN_MQA ? 1 : c.num_kv_heads);
+    if (m->nKV <= 0 || m->nH % m->nKV != 0) throw std::runtime_error("num_heads must be a multiple of num_kv_heads");
+    m->group = m->nH / m->nKV;
+    m->Vpad = (int)round_up(m->V, 128);
+    m->n_qkv = (m->nH + 2 * m->nKV) * m->hd;
+    m->Tmax = (int)round_up(c.max_seq_len, 64);
+    // score scale: GQA uses AttentionMultiplier when set (attention.go:361-364); MHA/MQA 1/sqrt(hd)
+    if (c.attention_type == NVL_ATTN_GQA && c.attention_multiplier != 0.f) m->attn_scale = c.attention_multiplier;
+    else m->attn_scale = 1.0f / std::sqrt((float)m->hd);
+    m->resid_alpha = c.residual_multiplier != 0.f ? c.residual_multiplier : 1.0f;
+    m->layers.resize(m->L);
+    if (m->opts.max_seqs <= 0) m->opts.max_seqs = 1;
+    if (m->opts.max_batch_tokens <= 0) m->opts.max_batch_tokens = c.max_seq_len;
+    *out = m;
+    return NVL_OK;
+    } catch (const HipError& e) {
+        std::string s = std::string("nvl_create: HIP error: ") + hipGetErrorString(e.code);
+        delete m;
+        return fail(nullptr, NVL_ERR_HIP, s);
+    } catch (const std::exception& e) {
+        std::string s = e.what();
+        delete m;
+        return fail(nullptr, NVL_ERR_INVALID, s);
+    }
+}
+
+extern "C" void nvl_destroy(nvl_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    for (int k = 0; k < NVL_T_COUNT; k++) dfree(m->g[k].p);
+    for (auto& l : m->layers) {
+        for (int k = 0; k < NVL_T_COUNT; k++) dfree(l.t[k].p);
+        dfree(l.w_qkv); dfree(l.b_qkv); dfree(l.w1); dfree(l.moe_in);
+    }
+    if (m->lm_head && m->lm_head != m->g[NVL_T_TOK_EMB].p && m->lm_head != m->g[NVL_T_LM_HEAD].p) dfree(m->lm_head);
+    dfree(m->rope_cos); dfree(m->rope_sin); dfree(m->kcache); dfree(m->vcache);
+    dfree(m->x); dfree(m->xn); dfree(m->qkv); dfree(m->q); dfree(m->attn_out); dfree(m->hbuf); dfree(m->h2);
+    dfree(m->xn_last); dfree(m->logits); dfree(m->argmax_dev); dfree(m->router_logits); dfree(m->expert_ids);
+    dfree(m->expert_w); dfree(m->seg_start); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo);
+    dfree(m->meta_dev); dfree(m->hidden);
+    if (m->meta_host) (void)hipHostFree(m->meta_host);
+    for (auto e : m->ev_pool) (void)hipEventDestroy(e);
+    if (m->ev0) (void)hipEventDestroy(m->ev0);
+    if (m->ev1) (void)hipEventDestroy(m->ev1);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+// =================================================================================================
+// weights
+// =================================================================================================
+namespace {
+
+// canonical device copy: 2-D -> [rows_pad(128)][K] in weight dtype; 1-D -> fp32
+void upload_2d(nvl_model* m, DevTensor* t, const void* data, int dtype, int64_t N, int64_t K, bool src_is_in_out) {
+    const size_t esz = dtype == NVL_DTYPE_F32 ? 4 : 2;
+    void* raw = dmalloc_bytes((int64_t)N * K * esz);
+    NVL_HIP(hipMemcpyAsync(raw, data, (size_t)N * K * esz, hipMemcpyDefault, m->stream));
+    const int64_t Npad = round_up(N, 128);
+    dfree(t->p);
+    t->p = dmalloc_bytes(Npad * K * (int64_t)m->wsize);
+    NVL_HIP(hipMemsetAsync(t->p, 0, (size_t)(Npad * K) * m->wsize, m->stream));
+    dim3 grid((unsigned)cdiv(K, 32), (unsigned)cdiv(N, 32));
+    if (m->f32)
+        hipLaunchKernelGGL((convert_2d_kernel<float>), grid, dim3(256), 0, m->stream, raw, dtype,
+                           src_is_in_out ? 1 : 0, (float*)t->p, N, K);
+    else
+        hipLaunchKernelGGL((convert_2d_kernel<bf16_t>), grid, dim3(256), 0, m->stream, raw, dtype,
+                           src_is_in_out ? 1 : 0, (bf16_t*)t->p, N, K);
+    NVL_HIP(hipGetLastError());
+    NVL_HIP(hipStreamSynchronize(m->stream));
+    dfree(raw);
+    t->rows = N; t->cols = K; t->rows_pad = Npad;
+    m->stats.weight_bytes += (double)Npad * K * m->wsize;
+}
+
+void upload_1d(nvl_model* m, DevTensor* t, const void* data, int dtype, int64_t n) {
+    const size_t esz = dtype == NVL_DTYPE_F32 ? 4 : 2;
+    void* raw = dmalloc_bytes(n * (int64_t)esz);
+    NVL_HIP(hipMemcpyAsync(raw, data, (size_t)n * esz, hipMemcpyDefault, m->stream));
+    dfree(t->p);
+    t->p = dmalloc<float>(n);
+    hipLaunchKernelGGL(convert_1d_kernel, dim3(cdiv(n, 256)), dim3(256), 0, m->stream, raw, dtype, (float*)t->p, n);
+    NVL_HIP(hipGetLastError());
+    NVL_HIP(hipStreamSynchronize(m->stream));
+    dfree(raw);
+    t->rows = n; t->cols = 1; t->rows_pad = n;
+    m->stats.weight_bytes += (double)n * 4;
+}
+
+int64_t expect_out(const nvl_model* m, int kind) {   // logical N (out features) per kind
+    switch (kind) {
+        case NVL_T_LM_HEAD: return m->V;
+        case NVL_T_WQ: return (int64_t)m->nH * m->hd;
+        case NVL_T_WK: case NVL_T_WV: return (int64_t)m->nKV * m->hd;
+        case NVL_T_WKV: return 2 * m->hd;
+        case NVL_T_WO: return m->H;
+        case NVL_T_W1: return m->cfg.activation_type == NVL_ACT_SWIGLU ? 2 * (int64_t)m->F : m->F;
+        case NVL_T_W2: return m->H;
+        case NVL_T_ROUTER: return m->cfg.num_experts;
+        default: return -1;
+    }
+}
+int64_t expect_in(const nvl_model* m, int kind) {
+    switch (kind) {
+        case NVL_T_WO: return (int64_t)m->nH * m->hd;
+        case NVL_T_W2: return m->F;
+        default: return m->H;
+    }
+}
+
+}  // namespace
+
+extern "C" int nvl_upload_tensor(nvl_model* m, int kind, int layer, const void* data, int dtype,
+                                 int64_t rows, int64_t cols, int layout) {
+    if (!m || !data) return fail(m, NVL_ERR_INVALID, "nvl_upload_tensor: null argument");
+    if (m->finalized) return fail(m, NVL_ERR_STATE, "nvl_upload_tensor: model already finalized");
+    if (dtype < 0 || dtype > 2) return fail(m, NVL_ERR_INVALID, "nvl_upload_tensor: unsupported dtype");
+    DevTensor* t = tensor_slot(m, kind, layer);
+    if (!t) return fail(m, NVL_ERR_INVALID, "nvl_upload_tensor: bad kind or layer");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    char buf[256];
+    if (is_1d(kind)) {
+        const int64_t n = rows * (cols > 0 ? cols : 1);
+        upload_1d(m, t, data, dtype, n);
+        return NVL_OK;
+    }
+    if (kind == NVL_T_TOK_EMB || kind == NVL_T_POS_EMB) {
+        const int64_t want_rows = kind == NVL_T_TOK_EMB ? m->V : rows;
+        if (cols != m->H || rows != want_rows) {
+            snprintf(buf, sizeof buf, "embedding shape [%lld,%lld] does not match [%lld,%d]", (long long)rows,
+                     (long long)cols, (long long)want_rows, m->H);
+            return fail(m, NVL_ERR_INVALID, buf);
+        }
+        upload_2d(m, t, data, dtype, rows, cols, false);
+        return NVL_OK;
+    }
+    if (kind == NVL_T_MOE_IN || kind == NVL_T_MOE_OUT) {
+        const int64_t E = m->cfg.num_experts;
+        const int64_t out = kind == NVL_T_MOE_IN ? 2 * (int64_t)m->F : m->H;
+        const int64_t in = kind == NVL_T_MOE_IN ? m->H : m->F;
+        if (rows != E * out || cols != in) {
+            snprintf(buf, sizeof buf, "MoE tensor shape [%lld,%lld] does not match [E*%lld,%lld]", (long long)rows,
+                     (long long)cols, (long long)out, (long long)in);
+            return fail(m, NVL_ERR_INVALID, buf);
+        }
+        upload_2d(m, t, data, dtype, rows, cols, false);
+        return NVL_OK;
+    }
+    const int64_t N = expect_out(m, kind), K = expect_in(m, kind);
+    if (N < 0) return fail(m, NVL_ERR_INVALID, "nvl_upload_tensor: kind is not a 2-D weight");
+    const int64_t got_in = layout == NVL_LAYOUT_IN_OUT ? rows : cols;
+    const int64_t got_out = layout == NVL_LAYOUT_IN_OUT ? cols : rows;
+    if (got_in != K || got_out != N) {   // reference: panic "incompatible shapes" tensor.go:67
+        snprintf(buf, sizeof buf, "weight kind %d: got [in=%lld,out=%lld], model needs [in=%lld,out=%lld]", kind,
+                 (long long)got_in, (long long)got_out, (long long)K, (long long)N);
+        return fail(m, NVL_ERR_INVALID, buf);
+    }
+    upload_2d(m, t, data, dtype, N, K, layout == NVL_LAYOUT_IN_OUT);
+    return NVL_OK;
+    NVL_CATCH(m)
+}
+
+// splitGPT2QKV (generic_loader.go:674-702): c_attn [H, 3H] is [in,out]; columns split Q|K|V.
+extern "C" int nvl_upload_gpt2_qkv(nvl_model* m, int layer, const float* w, const float* b) {
+    if (!m || !w) return fail(m, NVL_ERR_INVALID, "nvl_upload_gpt2_qkv: null argument");
+    const int64_t H = m->H;
+    std::vector<float> part((size_t)H * H);
+    const int kinds[3] = {NVL_T_WQ, NVL_T_WK, NVL_T_WV};
+    const int bk[3] = {NVL_T_BQ, NVL_T_BK, NVL_T_BV};
+    for (int s = 0; s < 3; s++) {
+        for (int64_t r = 0; r < H; r++)
+            memcpy(&part[(size_t)(r * H)], w + r * 3 * H + s * H, (size_t)H * sizeof(float));
+        int rc = nvl_upload_tensor(m, kinds[s], layer, part.data(), NVL_DTYPE_F32, H, H, NVL_LAYOUT_IN_OUT);
+        if (rc) return rc;
+        if (b) {   // generic_loader.go:418-427
+            rc = nvl_upload_tensor(m, bk[s], layer, b + s * H, NVL_DTYPE_F32, H, 1, 0);
+            if (rc) return rc;
+        }
+    }
+    return NVL_OK;
+}
+
+// splitFalconQKV + combineMQAKV (generic_loader.go:705-765): rows of [H, (nH+2)*hd] hold
+// [Q_0 .. Q_{nH-1} | K | V] chunks of hd.
+extern "C" int nvl_upload_falcon_qkv(nvl_model* m, int layer, const float* qkv) {
+    if (!m || !qkv) return fail(m, NVL_ERR_INVALID, "nvl_upload_falcon_qkv: null argument");
+    const int64_t H = m->H, nH = m->nH, hd = m->hd, roww = (nH + 2) * hd;
+    std::vector<float> q((size_t)(H * nH * hd)), kv((size_t)(H * 2 * hd));
+    for (int64_t r = 0; r < H; r++) {
+        memcpy(&q[(size_t)(r * nH * hd)], qkv + r * roww, (size_t)(nH * hd) * sizeof(float));
+        memcpy(&kv[(size_t)(r * 2 * hd)], qkv + r * roww + nH * hd, (size_t)(2 * hd) * sizeof(float));
+    }
+    int rc = nvl_upload_tensor(m, NVL_T_WQ, layer, q.data(), NVL_DTYPE_F32, H, nH * hd, NVL_LAYOUT_IN_OUT);
+    if (rc) return rc;
+    return nvl_upload_tensor(m, NVL_T_WKV, layer, kv.data(), NVL_DTYPE_F32, H, 2 * hd, NVL_LAYOUT_IN_OUT);
+}
+
+namespace {
+
+void gather_rows(nvl_model* m, const void* src, const std::vector<int32_t>& idx, void* dst, int64_t K) {
+    int32_t* didx = dmalloc<int32_t>((int64_t)idx.size());
+    NVL_HIP(hipMemcpyAsync(didx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, m->stream));
+    if (m->f32)
+        hipLaunchKernelGGL((gather_rows_kernel<float>), dim3((unsigned)idx.size()), dim3(256), 0, m->stream,
+                           (const float*)src, didx, (float*)dst, K);
+    else
+        hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3((unsigned)idx.size()), dim3(256), 0, m->stream,
+                           (const bf16_t*)src, didx, (bf16_t*)dst, K);
+    NVL_HIP(hipGetLastError());
+    NVL_HIP(hipStreamSynchronize(m->stream));
+    dfree(didx);
+}
+
+// interleave [gate F rows | up F rows] into blocks of 16: [g0..15 | u0..15 | g16..31 | ...]
+std::vector<int32_t> swiglu_interleave(int64_t F, int64_t src_base) {
+    std::vector<int32_t> idx((size_t)(2 * F));
+    for (int64_t b = 0; b < F / 16; b++)
+        for (int c = 0; c < 16; c++) {
+            idx[(size_t)(32 * b + c)] = (int32_t)(src_base + 16 * b + c);
+            idx[(size_t)(32 * b + 16 + c)] = (int32_t)(src_base + F + 16 * b + c);
+        }
+    return idx;
+}
+
+}  // namespace
+
+extern "C" int nvl_finalize(nvl_model* m) {
+    if (!m) return NVL_ERR_INVALID;
+    if (m->finalized) return fail(m, NVL_ERR_STATE, "nvl_finalize: already finalized");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    const nvl_model_config& c = m->cfg;
+    const int64_t H = m->H, hd = m->hd;
+    auto need = [&](bool ok, const char* what) { if (!ok) throw std::runtime_error(std::string("nvl_finalize: missing tensor: ") + what); };
+    need(m->g[NVL_T_TOK_EMB].present(), "token embedding");
+    need(m->g[NVL_T_FINAL_NORM_W].present(), "final norm weight");
+    if (c.norm_type == NVL_NORM_LAYER) need(m->g[NVL_T_FINAL_NORM_B].present(), "final norm bias (LayerNorm)");
+
+    for (int li = 0; li < m->L; li++) {
+        LayerW& l = m->layers[li];
+        need(l.t[NVL_T_ATTN_NORM_W].present(), "attention/input norm weight");
+        need(l.t[NVL_T_WQ].present() && l.t[NVL_T_WO].present(), "attention Q/O projection");
+        const bool mqa = c.attention_type == NVL_ATTN_MQA;
+        if (mqa) need(l.t[NVL_T_WKV].present(), "MQA fused KV projection");
+        else need(l.t[NVL_T_WK].present() && l.t[NVL_T_WV].present(), "K/V projection");
+        if (c.block_style == NVL_BLOCK_SEQUENTIAL) need(l.t[NVL_T_FFN_NORM_W].present(), "FFN norm weight");
+        // ---- fused QKV [n_qkv_pad][H]: rows Q | K | V (canonical rows are contiguous: plain copies)
+        const int64_t nq = (int64_t)m->nH * hd, nkv = (int64_t)m->nKV * hd;
+        const int64_t npad = round_up(m->n_qkv, 128);
+        l.w_qkv = dmalloc_bytes(npad * H * (int64_t)m->wsize);
+        NVL_HIP(hipMemsetAsync(l.w_qkv, 0, (size_t)(npad * H) * m->wsize, m->stream));
+        char* dst = (char*)l.w_qkv;
+        const size_t rowb = (size_t)H * m->wsize;
+        NVL_HIP(hipMemcpyAsync(dst, l.t[NVL_T_WQ].p, nq * rowb, hipMemcpyDeviceToDevice, m->stream));
+        if (mqa) {
+            NVL_HIP(hipMemcpyAsync(dst + nq * rowb, l.t[NVL_T_WKV].p, 2 * hd * rowb, hipMemcpyDeviceToDevice, m->stream));
+        } else {
+            NVL_HIP(hipMemcpyAsync(dst + nq * rowb, l.t[NVL_T_WK].p, nkv * rowb, hipMemcpyDeviceToDevice, m->stream));
+            NVL_HIP(hipMemcpyAsync(dst + (nq + nkv) * rowb, l.t[NVL_T_WV].p, nkv * rowb, hipMemcpyDeviceToDevice, m->stream));
+        }
+        l.n_qkv = m->n_qkv;
+        if (l.t[NVL_T_BQ].present() || l.t[NVL_T_BK].present() || l.t[NVL_T_BV].present()) {
+            l.b_qkv = dmalloc<float>(m->n_qkv);
+            NVL_HIP(hipMemsetAsync(l.b_qkv, 0, (size_t)m->n_qkv * 4, m->stream));
+            if (l.t[NVL_T_BQ].present()) NVL_HIP(hipMemcpyAsync(l.b_qkv, l.t[NVL_T_BQ].p, nq * 4, hipMemcpyDeviceToDevice, m->stream));
+            if (l.t[NVL_T_BK].present()) NVL_HIP(hipMemcpyAsync(l.b_qkv + nq, l.t[NVL_T_BK].p, nkv * 4, hipMemcpyDeviceToDevice, m->stream));
+            if (l.t[NVL_T_BV].present()) NVL_HIP(hipMemcpyAsync(l.b_qkv + nq + nkv, l.t[NVL_T_BV].p, nkv * 4, hipMemcpyDeviceToDevice, m->stream));
+        }
+        NVL_HIP(hipStreamSynchronize(m->stream));
+        for (int k : {NVL_T_WQ, NVL_T_WK, NVL_T_WV, NVL_T_WKV}) { dfree(l.t[k].p); l.t[k].p = nullptr; }
+
+        // ---- FFN / MoE
+        if (c.use_moe) {
+            need(l.t[NVL_T_ROUTER].present() && l.t[NVL_T_MOE_IN].present() && l.t[NVL_T_MOE_OUT].present(), "MoE tensors");
+            if (!m->f32) {   // interleave gate/up rows per expert for the fused SwiGLU epilogue
+                const int64_t E = c.num_experts, I = m->F;
+                std::vector<int32_t> idx;
+                idx.reserve((size_t)(E * 2 * I));
+                for (int64_t e = 0; e < E; e++) {
+                    auto one = swiglu_interleave(I, e * 2 * I);
+                    idx.insert(idx.end(), one.begin(), one.end());
+                }
+                l.moe_in = dmalloc_bytes(E * 2 * I * H * (int64_t)m->wsize);
+                gather_rows(m, l.t[NVL_T_MOE_IN].p, idx, l.moe_in, H);
+                dfree(l.t[NVL_T_MOE_IN].p); l.t[NVL_T_MOE_IN].p = nullptr;
+            } else {
+                l.moe_in = l.t[NVL_T_MOE_IN].p; l.t[NVL_T_MOE_IN].p = nullptr;
+            }
+        } else {
+            need(l.t[NVL_T_W1].present() && l.t[NVL_T_W2].present(), "FFN weights");
+            const bool swiglu = c.activation_type == NVL_ACT_SWIGLU;
+            l.n1 = swiglu ? 2 * m->F : m->F;
+            if (swiglu && !m->f32) {
+                auto idx = swiglu_interleave(m->F, 0);
+                const int64_t np = round_up(l.n1, 128);
+                idx.resize((size_t)np, -1);
+                l.w1 = dmalloc_bytes(np * H * (int64_t)m->wsize);
+                gather_rows(m, l.t[NVL_T_W1].p, idx, l.w1, H);
+                dfree(l.t[NVL_T_W1].p); l.t[NVL_T_W1].p = nullptr;
+            } else {
+                l.w1 = l.t[NVL_T_W1].p; l.t[NVL_T_W1].p = nullptr;
+            }
+        }
+    }
+    // ---- LM head: tied (or absent) => the token embedding itself, already [Vpad][H] K-contiguous
+    if (!c.tied_embedding && m->g[NVL_T_LM_HEAD].present()) m->lm_head = m->g[NVL_T_LM_HEAD].p;
+    else m->lm_head = m->g[NVL_T_TOK_EMB].p;   // generic_loader.go:255-259
+
+    // ---- RoPE tables in fp64 on the host, exactly as NewRoPECache (rope.go:18-50)
+    bool rope = false; double base = c.rope_base;
+    if (c.attention_type == NVL_ATTN_MQA) { rope = true; base = 10000.0; }           // mqa.go:35
+    else if (c.attention_type == NVL_ATTN_GQA && c.position_type == NVL_POS_ROPE) rope = true;
+    if (rope) {
+        const int half = (int)hd / 2;
+        std::vector<float> ct((size_t)c.max_seq_len * hd), stt((size_t)c.max_seq_len * hd);
+        for (int pos = 0; pos < c.max_seq_len; pos++)
+            for (int i = 0; i < half; i++) {
+                const double freq = 1.0 / std::pow(base, (double)(2 * i) / (double)hd);
+                const double ang = (double)pos * freq;
+                const float cv = (float)std::cos(ang), sv = (float)std::sin(ang);
+                ct[(size_t)pos * hd + i] = cv; ct[(size_t)pos * hd + half + i] = cv;
+                stt[(size_t)pos * hd + i] = sv; stt[(size_t)pos * hd + half + i] = sv;
+            }
+        m->rope_cos = dmalloc<float>((int64_t)ct.size());
+        m->rope_sin = dmalloc<float>((int64_t)stt.size());
+        NVL_HIP(hipMemcpy(m->rope_cos, ct.data(), ct.size() * 4, hipMemcpyHostToDevice));
+        NVL_HIP(hipMemcpy(m->rope_sin, stt.data(), stt.size() * 4, hipMemcpyHostToDevice));
+    }
+
+    // ---- KV slabs: [slot][layer][kv head][Tmax][hd]; zero-filled so stale tiles hold finite values
+    m->layer_stride = (int64_t)m->nKV * m->Tmax * hd;
+    m->slot_stride = m->layer_stride * m->L;
+    const int64_t kv_elems = m->slot_stride * m->opts.max_seqs;
+    m->kcache = dmalloc_bytes(kv_elems * (int64_t)m->wsize);
+    m->vcache = dmalloc_bytes(kv_elems * (int64_t)m->wsize);
+    NVL_HIP(hipMemset(m->kcache, 0, (size_t)kv_elems * m->wsize));
+    NVL_HIP(hipMemset(m->vcache, 0, (size_t)kv_elems * m->wsize));
+    m->slot_len.assign((size_t)m->opts.max_seqs, 0);
+    m->free_slots.clear();
+    for (int s = m->opts.max_seqs - 1; s >= 0; s--) m->free_slots.push_back(s);
+
+    // ---- workspaces
+    const int64_t Mmax = m->opts.max_batch_tokens, S = m->opts.max_seqs;
+    const int64_t qw = (int64_t)m->nH * hd;
+    m->x = dmalloc<float>(Mmax * H);
+    m->xn = dmalloc_bytes(Mmax * H * (int64_t)m->wsize);
+    m->qkv = dmalloc<float>(Mmax * m->n_qkv);
+    m->q = dmalloc_bytes(Mmax * qw * (int64_t)m->wsize);
+    m->attn_out = dmalloc_bytes(Mmax * qw * (int64_t)m->wsize);
+    const int64_t k = c.use_moe ? c.num_experts_per_tok : 1;
+    m->hbuf = dmalloc_bytes(Mmax * k * m->F * (int64_t)m->wsize);
+    if (m->f32 && (c.activation_type == NVL_ACT_SWIGLU || c.use_moe)) m->h2 = dmalloc<float>(Mmax * k * 2 * m->F);
+    m->xn_last = dmalloc_bytes(S * H * (int64_t)m->wsize);
+    m->logit_rows = S;
+    m->logits = dmalloc<float>(S * (int64_t)m->Vpad);
+    m->argmax_dev = dmalloc<int32_t>(std::max<int64_t>(S, Mmax));
+    if (c.use_moe) {
+        m->router_logits = dmalloc<float>(Mmax * 128);
+        m->expert_ids = dmalloc<int32_t>(Mmax * k);
+        m->expert_w = dmalloc<float>(Mmax * k);
+        m->seg_start = dmalloc<int32_t>(c.num_experts + 1);
+        m->perm_token = dmalloc<int32_t>(Mmax * k);
+        m->slot_of = dmalloc<int32_t>(Mmax * k);
+        m->moe_eo = dmalloc<float>(Mmax * k * H);
+    }
+    m->meta_ints = 3 * Mmax + 5 * S + 16;
+    NVL_HIP(hipHostMalloc((void**)&m->meta_host, (size_t)m->meta_ints * 4, hipHostMallocDefault));
+    m->meta_dev = dmalloc<int32_t>(m->meta_ints);
+    m->finalized = true;
+    return NVL_OK;
+    NVL_CATCH(m)
+}
+
+// =================================================================================================
+// sequences
+// =================================================================================================
+extern "C" int nvl_seq_open(nvl_model* m, int64_t seq_id) {
+    if (!m || !m->finalized) return fail(m, NVL_ERR_STATE, "nvl_seq_open: model not finalized");
+    if (m->seq_slot.count(seq_id)) return NVL_OK;
+    if (m->free_slots.empty()) return fail(m, NVL_ERR_NO_SLOT, "nvl_seq_open: all KV slots in use");
+    const int s = m->free_slots.back(); m->free_slots.pop_back();
+    m->seq_slot[seq_id] = s; m->slot_len[(size_t)s] = 0;
+    return NVL_OK;
+}
+extern "C" int nvl_seq_reset(nvl_model* m, int64_t seq_id) {
+    const int rc = nvl_seq_open(m, seq_id);
+    if (rc) return rc;
+    m->slot_len[(size_t)m->seq_slot[seq_id]] = 0;
+    return NVL_OK;
+}
+extern "C" int nvl_seq_close(nvl_model* m, int64_t seq_id) {
+    if (!m) return NVL_ERR_INVALID;
+    auto it = m->seq_slot.find(seq_id);
+    if (it == m->seq_slot.end()) return NVL_OK;   // delete() of a missing key is a no-op in Go
+    m->free_slots.push_back(it->second);
+    m->seq_slot.erase(it);
+    return NVL_OK;
+}
+extern "C" int nvl_seq_close_all(nvl_model* m) {
+    if (!m) return NVL_ERR_INVALID;
+    for (auto& kv : m->seq_slot) m->free_slots.push_back(kv.second);
+    m->seq_slot.clear();
+    return NVL_OK;
+}
+extern "C" int nvl_seq_len(nvl_model* m, int64_t seq_id) {
+    if (!m) return NVL_ERR_INVALID;
+    auto it = m->seq_slot.find(seq_id);
+    if (it == m->seq_slot.end()) return NVL_ERR_UNKNOWN_SEQ;
+    return m->slot_len[(size_t)it->second];
+}
+
+// =================================================================================================
+// forward
+// =================================================================================================
+namespace {
+
+struct Meta {   // device pointers into meta_dev
+    int32_t *tokens, *tok_pos, *tok_slot, *seq_tok_start, *seq_len, *seq_pos, *seq_slot, *last_rows;
+};
+
+template <typename ActT>
+void launch_norm(nvl_model* m, const float* x, const int32_t* rows_idx, const float* w, const float* b,
+                 void* y, int rows) {
+    KScope ks(m, KC_OTHER);
+    hipLaunchKernelGGL((norm_kernel<ActT>), dim3(cdiv(rows, 4)), dim3(256), 0, m->stream, x, rows_idx, w, b,
+                       m->cfg.norm_eps, (ActT*)y, rows, m->H);
+}
+void norm(nvl_model* m, const float* x, const int32_t* rows_idx, const DevTensor& w, const DevTensor& b, void* y, int rows) {
+    if (m->f32) launch_norm<float>(m, x, rows_idx, (const float*)w.p, (const float*)b.p, y, rows);
+    else launch_norm<bf16_t>(m, x, rows_idx, (const float*)w.p, (const float*)b.p, y, rows);
+    NVL_HIP(hipGetLastError());
+}
+
+void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, double flops) {
+    AttnArgs a{};
+    a.q = m->q; a.q_stride = m->nH * m->hd;
+    a.out = m->attn_out; a.out_stride = m->nH * m->hd;
+    a.kcache = (char*)m->kcache + (size_t)li * m->layer_stride * m->wsize;
+    a.vcache = (char*)m->vcache + (size_t)li * m->layer_stride * m->wsize;
+    a.slot_stride = m->slot_stride; a.Tmax = m->Tmax;
+    a.seq_tok_start = md.seq_tok_start; a.seq_len = md.seq_len; a.seq_pos = md.seq_pos; a.seq_slot = md.seq_slot;
+    a.nH = m->nH; a.nKV = m->nKV; a.group = m->group; a.scale = m->attn_scale;
+    KScope ks(m, KC_ATTN, flops);
+    if (m->f32) {
+        const size_t lds = (size_t)m->Tmax * 4;
+        hipLaunchKernelGGL(attn_f32_kernel, dim3(max_len, m->nH, n_seqs), dim3(256), lds, m->stream, a, m->hd);
+    } else {
+        const int qtiles = cdiv((int64_t)max_len * m->group, 64);
+        dim3 grid(qtiles, m->nKV, n_seqs);
+        if (m->hd == 64) hipLaunchKernelGGL((attn_bf16_kernel<64>), grid, dim3(256), 0, m->stream, a);
+        else hipLaunchKernelGGL((attn_bf16_kernel<128>), grid, dim3(256), 0, m->stream, a);
+    }
+    NVL_HIP(hipGetLastError());
+}
+
+void rope_kv(nvl_model* m, int li, const Meta& md, int M) {
+    KScope ks(m, KC_OTHER);
+    dim3 grid(M, m->nH + 2 * m->nKV);
+    const int thr = m->hd / 2;
+    void* kc = (char*)m->kcache + (size_t)li * m->layer_stride * m->wsize;
+    void* vc = (char*)m->vcache + (size_t)li * m->layer_stride * m->wsize;
+    if (m->f32)
+        hipLaunchKernelGGL((rope_kv_kernel<float, false>), grid, dim3(thr), 0, m->stream, m->qkv, m->n_qkv,
+                           md.tok_pos, md.tok_slot, m->rope_cos, m->rope_sin, (float*)m->q, m->nH * m->hd,
+                           (float*)kc, (float*)vc, m->slot_stride, m->Tmax, m->nH, m->nKV, m->hd);
+    else
+        hipLaunchKernelGGL((rope_kv_kernel<bf16_t, true>), grid, dim3(thr), 0, m->stream, m->qkv, m->n_qkv,
+                           md.tok_pos, md.tok_slot, m->rope_cos, m->rope_sin, (bf16_t*)m->q, m->nH * m->hd,
+                           (bf16_t*)kc, (bf16_t*)vc, m->slot_stride, m->Tmax, m->nH, m->nKV, m->hd);
+    NVL_HIP(hipGetLastError());
+}
+
+GemmArgs mk(const void* A, int lda, const void* W, void* C, int ldc, const float* bias, float alpha, int M, int N, int K) {
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.a_rows = nullptr; a.W = W; a.C = C; a.ldc = ldc; a.bias = bias; a.alpha = alpha;
+    a.M = M; a.N = N; a.K = K; a.seg = nullptr;
+    return a;
+}
+
+// FeedForward.Forward (transformer.go:40-96) up to (not including) the W2 projection:
+// leaves act(x·W1) in m->hbuf [M][F]
+void ffn_up(nvl_model* m, const LayerW& l, int M) {
+    const bool swiglu = m->cfg.activation_type == NVL_ACT_SWIGLU;
+    const float* b1 = (const float*)l.t[NVL_T_B1].p;
+    if (swiglu) {
+        if (m->f32) {
+            gemm(m, EPI_STORE, true, mk(m->xn, m->H, l.w1, m->h2, 2 * m->F, nullptr, 1.f, M, 2 * m->F, m->H));
+            KScope ks(m, KC_OTHER);
+            const int64_t n = (int64_t)M * m->F;
+            hipLaunchKernelGGL((swiglu_kernel<float>), dim3(cdiv(n, 256)), dim3(256), 0, m->stream, m->h2,
+                               (float*)m->hbuf, (int64_t)M, m->F);
+            NVL_HIP(hipGetLastError());
+        } else {
+            gemm(m, EPI_SWIGLU, false, mk(m->xn, m->H, l.w1, m->hbuf, m->F, nullptr, 1.f, M, 2 * m->F, m->H));
+        }
+    } else {
+        gemm(m, EPI_GELU, false, mk(m->xn, m->H, l.w1, m->hbuf, m->F, b1, 1.f, M, m->F, m->H));
+    }
+}
+
+// MoELayer.Forward (moe.go:43-128): router GEMM -> route -> sort by expert -> per-expert GEMMs on
+// row segments -> combine in rank order into x (with the residual multiplier).
+void moe(nvl_model* m, const LayerW& l, int M) {
+    const nvl_model_config& c = m->cfg;
+    const int E = c.num_experts, k = c.num_experts_per_tok, I = m->F, H = m->H;
+    gemm(m, EPI_STORE, true, mk(m->xn, H, l.t[NVL_T_ROUTER].p, m->router_logits, 128, nullptr, 1.f, M, E, H));
+    {
+        KScope ks(m, KC_OTHER);
+        hipLaunchKernelGGL(moe_route_kernel, dim3(cdiv(M, 4)), dim3(256), 0, m->stream, m->router_logits, 128, M, E, k,
+                           m->expert_ids, m->expert_w);
+        hipLaunchKernelGGL(moe_sort_kernel, dim3(1), dim3(1024), 0, m->stream, m->expert_ids, M * k, E, k, m->seg_start,
+                           m->perm_token, m->slot_of);
+        NVL_HIP(hipGetLastError());
+    }
+    const int pairs = M * k;
+    // one launch per expert; the row segment [seg_start[e], seg_start[e+1]) is read on the device, the
+    // grid is bounded by M (a token picks an expert at most once) and surplus blocks exit at once.
+    for (int e = 0; e < E; e++) {
+        const char* win = (const char*)l.moe_in + (size_t)e * 2 * I * H * m->wsize;
+        GemmArgs a = m->f32 ? mk(m->xn, H, win, m->h2, 2 * I, nullptr, 1.f, M, 2 * I, H)
+                            : mk(m->xn, H, win, m->hbuf, I, nullptr, 1.f, M, 2 * I, H);
+        a.a_rows = m->perm_token; a.seg = m->seg_start + e;
+        gemm(m, m->f32 ? EPI_STORE : EPI_SWIGLU, m->f32, a);
+    }
+    if (m->f32) {
+        KScope ks(m, KC_OTHER);
+        const int64_t n = (int64_t)pairs * I;
+        hipLaunchKernelGGL((swiglu_kernel<float>), dim3(cdiv(n, 256)), dim3(256), 0, m->stream, m->h2, (float*)m->hbuf,
+                           (int64_t)pairs, I);
+        NVL_HIP(hipGetLastError());
+    }
+    for (int e = 0; e < E; e++) {
+        const char* wout = (const char*)l.t[NVL_T_MOE_OUT].p + (size_t)e * H * I * m->wsize;
+        GemmArgs a = mk(m->hbuf, I, wout, m->moe_eo, H, nullptr, 1.f, M, H, I);
+        a.seg = m->seg_start + e;
+        gemm(m, EPI_STORE, true, a);
+    }
+    {
+        KScope ks(m, KC_OTHER);
+        hipLaunchKernelGGL(moe_combine_kernel, dim3(M), dim3(256), 0, m->stream, m->moe_eo, m->slot_of, m->expert_w, k,
+                           c.residual_multiplier, m->x, H, 1);
+        NVL_HIP(hipGetLastError());
+    }
+}
+
+}  // namespace
+
+extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* tokens,
+                           const int32_t* seq_lens, const int32_t* pos_offsets, uint32_t flags,
+                           float* logits_out, int32_t* argmax_out) {
+    if (!m) return NVL_ERR_INVALID;
+    if (!m->finalized) return fail(m, NVL_ERR_STATE, "nvl_forward: model not finalized");
+    if (n_seqs <= 0 || !seq_ids || !tokens || !seq_lens || !pos_offsets)
+        return fail(m, NVL_ERR_INVALID, "nvl_forward: null/empty arguments");
+    if (n_seqs > m->opts.max_seqs) return fail(m, NVL_ERR_INVALID, "nvl_forward: n_seqs exceeds max_seqs");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    const nvl_model_config& c = m->cfg;
+    const int H = m->H;
+    // ---- validate + build metadata -------------------------------------------------------
+    int64_t M64 = 0; int max_len = 0; bool prefill = false;
+    for (int i = 0; i < n_seqs; i++) {
+        if (seq_lens[i] <= 0) return fail(m, NVL_ERR_INVALID, "nvl_forward: empty sequence");
+        M64 += seq_lens[i]; max_len = std::max(max_len, seq_lens[i]);
+        if (seq_lens[i] > 1) prefill = true;
+    }
+    if (M64 > m->opts.max_batch_tokens) return fail(m, NVL_ERR_INVALID, "nvl_forward: batch exceeds max_batch_tokens");
+    const int M = (int)M64;
+    int32_t* h = m->meta_host;
+    const int64_t Mmax = m->opts.max_batch_tokens, S = m->opts.max_seqs;
+    (void)Mmax;
+    int32_t *h_sts = h, *h_len = h_sts + S, *h_pos = h_len + S, *h_slot = h_pos + S, *h_last = h_slot + S,
+            *h_tokens = h + 5 * S, *h_tok_pos = h_tokens + M, *h_tok_slot = h_tok_pos + M;
+    int t = 0;
+    for (int i = 0; i < n_seqs; i++) {
+        auto it = m->seq_slot.find(seq_ids[i]);
+        if (it == m->seq_slot.end()) return fail(m, NVL_ERR_UNKNOWN_SEQ, "nvl_forward: sequence has no KV slot (nvl_seq_open first)");
+        const int slot = it->second;
+        for (int j = 0; j < i; j++) if (seq_ids[j] == seq_ids[i]) return fail(m, NVL_ERR_INVALID, "nvl_forward: duplicate sequence in batch");
+        if (pos_offsets[i] != m->slot_len[(size_t)slot]) return fail(m, NVL_ERR_INVALID, "nvl_forward: pos_offset does not equal the cached length");
+        if (pos_offsets[i] + seq_lens[i] > c.max_seq_len)   // rope.go:84-86 / :176-178 panic
+            return fail(m, NVL_ERR_POSITION, "nvl_forward: position exceeds max_seq_len");
+        h_sts[i] = t; h_len[i] = seq_lens[i]; h_pos[i] = pos_offsets[i]; h_slot[i] = slot;
+        for (int j = 0; j < seq_lens[i]; j++, t++) {
+            const int tok = tokens[t];
+            if (tok < 0 || tok >= m->V) return fail(m, NVL_ERR_INVALID, "nvl_forward: token id out of range");
+            h_tokens[t] = tok; h_tok_pos[t] = pos_offsets[i] + j; h_tok_slot[t] = slot;
+        }
+        h_last[i] = t - 1;
+    }
+    Meta md;
+    md.seq_tok_start = m->meta_dev; md.seq_len = md.seq_tok_start + S; md.seq_pos = md.seq_len + S;
+    md.seq_slot = md.seq_pos + S; md.last_rows = md.seq_slot + S;
+    md.tokens = m->meta_dev + 5 * S; md.tok_pos = md.tokens + M; md.tok_slot = md.tok_pos + M;
+    NVL_HIP(hipEventRecord(m->ev0, m->stream));
+    NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, (size_t)(5 * S + 3 * (int64_t)M) * 4, hipMemcpyHostToDevice, m->stream));
+
+    if (m->keep_hidden && m->hidden_tokens < M) {
+        dfree(m->hidden);
+        m->hidden = dmalloc<float>((int64_t)m->L * M * H);
+        m->hidden_tokens = M;
+    }
+    m->hidden_last_M = M;
+
+    // ---- embed (generic_model.go:295-302) -------------------------------------------------
+    {
+        KScope ks(m, KC_OTHER);
+        const void* pe = (c.position_type == NVL_POS_LEARNED) ? m->g[NVL_T_POS_EMB].p : nullptr;
+        const int pe_rows = pe ? (int)std::min<int64_t>(m->g[NVL_T_POS_EMB].rows, c.max_seq_len) : 0;
+        if (m->f32)
+            hipLaunchKernelGGL((embed_kernel<float>), dim3(M), dim3(256), 0, m->stream, md.tokens, md.tok_pos,
+                               (const float*)m->g[NVL_T_TOK_EMB].p, (const float*)pe, pe_rows, c.embedding_multiplier, m->x, H);
+        else
+            hipLaunchKernelGGL((embed_kernel<bf16_t>), dim3(M), dim3(256), 0, m->stream, md.tokens, md.tok_pos,
+                               (const bf16_t*)m->g[NVL_T_TOK_EMB].p, (const bf16_t*)pe, pe_rows, c.embedding_multiplier, m->x, H);
+        NVL_HIP(hipGetLastError());
+    }
+
+    // attention FLOPs of this call (4*hd per (query, visible key) pair per head)
+    double attn_flops = 0;
+    for (int i = 0; i < n_seqs; i++) {
+        const double s = seq_lens[i], p0 = pos_offsets[i];
+        attn_flops += 4.0 * m->hd * m->nH * (s * p0 + s * (s + 1) / 2);
+    }
+    const int qw = m->nH * m->hd;
+    const bool parallel = c.block_style == NVL_BLOCK_PARALLEL;
+
+    for (int li = 0; li < m->L; li++) {
+        const LayerW& l = m->layers[li];
+        norm(m, m->x, nullptr, l.t[NVL_T_ATTN_NORM_W], l.t[NVL_T_ATTN_NORM_B], m->xn, M);
+        gemm(m, EPI_STORE, true, mk(m->xn, H, l.w_qkv, m->qkv, m->n_qkv, l.b_qkv, 1.f, M, m->n_qkv, H));
+        rope_kv(m, li, md, M);
+        attention(m, li, md, n_seqs, max_len, attn_flops);
+        const float* bo = (const float*)l.t[NVL_T_BO].p;
+        if (parallel) {
+            // generic_model.go:395-418: r + [am*]attn + [rm*]ffn, both branches read the same normed x
+            const bool mults = c.attention_multiplier != 0.f && c.residual_multiplier != 0.f;
+            ffn_up(m, l, M);
+            gemm(m, EPI_RESID, true, mk(m->attn_out, qw, l.t[NVL_T_WO].p, m->x, H, bo, mults ? c.attention_multiplier : 1.f, M, H, qw));
+            gemm(m, EPI_RESID, true, mk(m->hbuf, m->F, l.t[NVL_T_W2].p, m->x, H, (const float*)l.t[NVL_T_B2].p,
+                                        mults ? c.residual_multiplier : 1.f, M, H, m->F));
+        } else {
+            gemm(m, EPI_RESID, true, mk(m->attn_out, qw, l.t[NVL_T_WO].p, m->x, H, bo, m->resid_alpha, M, H, qw));
+            norm(m, m->x, nullptr, l.t[NVL_T_FFN_NORM_W], l.t[NVL_T_FFN_NORM_B], m->xn, M);
+            if (c.use_moe) {
+                moe(m, l, M);
+            } else {
+                ffn_up(m, l, M);
+                gemm(m, EPI_RESID, true, mk(m->hbuf, m->F, l.t[NVL_T_W2].p, m->x, H, (const float*)l.t[NVL_T_B2].p,
+                                            m->resid_alpha, M, H, m->F));
+            }
+        }
+        if (m->keep_hidden)
+            NVL_HIP(hipMemcpyAsync(m->hidden + (int64_t)li * M * H, m->x, (size_t)M * H * 4, hipMemcpyDeviceToDevice, m->stream));
+    }
+
+    // ---- final norm + LM head on the rows the caller keeps (generic_model.go:464-477, :595-604) ----
+    const bool all = (flags & NVL_FWD_ALL_LOGITS) != 0;
+    const int rows = all ? M : n_seqs;
+    if (rows > m->logit_rows) {
+        dfree(m->logits); dfree(m->xn_last);
+        m->logits = dmalloc<float>((int64_t)rows * m->Vpad);
+        m->xn_last = dmalloc_bytes((int64_t)rows * H * (int64_t)m->wsize);
+        m->logit_rows = rows;
+    }
+    norm(m, m->x, all ? nullptr : md.last_rows, m->g[NVL_T_FINAL_NORM_W], m->g[NVL_T_FINAL_NORM_B], m->xn_last, rows);
+    gemm(m, EPI_STORE, true, mk(m->xn_last, H, m->lm_head, m->logits, m->Vpad, nullptr, 1.f, rows, m->V, H));
+    {
+        KScope ks(m, KC_OTHER);
+        hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, m->stream, m->logits, m->Vpad, m->V,
+                           c.logits_scaling, m->argmax_dev);
+        NVL_HIP(hipGetLastError());
+    }
+    NVL_HIP(hipEventRecord(m->ev1, m->stream));
+    std::vector<int32_t> am((size_t)rows);
+    NVL_HIP(hipMemcpyAsync(am.data(), m->argmax_dev, (size_t)rows * 4, hipMemcpyDeviceToHost, m->stream));
+    if (logits_out)
+        NVL_HIP(hipMemcpy2DAsync(logits_out, (size_t)m->V * 4, m->logits, (size_t)m->Vpad * 4, (size_t)m->V * 4,
+                                 (size_t)rows, hipMemcpyDeviceToHost, m->stream));
+    NVL_HIP(hipStreamSynchronize(m->stream));
+    if (argmax_out) {
+        if (all) for (int i = 0; i < n_seqs; i++) argmax_out[i] = am[(size_t)h_last[i]];
+        else for (int i = 0; i < n_seqs; i++) argmax_out[i] = am[(size_t)i];
+    }
+    for (int i = 0; i < n_seqs; i++) m->slot_len[(size_t)h_slot[i]] += seq_lens[i];
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, m->ev0, m->ev1);
+    m->stats.forward_calls++;
+    if (prefill) { m->stats.prefill_tokens += (uint64_t)M; m->stats.prefill_ms += ms; }
+    else { m->stats.decode_tokens += (uint64_t)M; m->stats.decode_ms += ms; }
+    if (m->profile) drain_profile(m);
+    return NVL_OK;
+    NVL_CATCH(m)
+}
+
+// =================================================================================================
+// debug / parity taps, stats
+// =================================================================================================
+extern "C" int nvl_set_debug(nvl_model* m, int keep_hidden) {
+    if (!m) return NVL_ERR_INVALID;
+    m->keep_hidden = keep_hidden != 0;
+    return NVL_OK;
+}
+extern "C" int nvl_get_hidden(nvl_model* m, int layer, float* out, int64_t n_floats) {
+    if (!m || !out) return NVL_ERR_INVALID;
+    if (!m->hidden || layer < 0 || layer >= m->L) return fail(m, NVL_ERR_STATE, "nvl_get_hidden: nothing recorded");
+    NVL_TRY(m)
+    const int64_t per = (int64_t)m->hidden_last_M * m->H;   // [L][M][H] of the recording call
+    if (n_floats > per) n_floats = per;
+    NVL_HIP(hipMemcpy(out, m->hidden + (int64_t)layer * per, (size_t)n_floats * 4, hipMemcpyDeviceToHost));
+    return NVL_OK;
+    NVL_CATCH(m)
+}
+
+extern "C" int nvl_get_kv(nvl_model* m, int64_t seq_id, int layer, float* k_out, float* v_out) {
+    if (!m) return NVL_ERR_INVALID;
+    auto it = m->seq_slot.find(seq_id);
+    if (it == m->seq_slot.end()) return fail(m, NVL_ERR_UNKNOWN_SEQ, "nvl_get_kv: unknown sequence");
+    if (layer < 0 || layer >= m->L) return fail(m, NVL_ERR_INVALID, "nvl_get_kv: bad layer");
+    NVL_TRY(m)
+    const int slot = it->second, T = m->slot_len[(size_t)slot], hd = m->hd, Tmax = m->Tmax;
+    const int64_t n = m->layer_stride;
+    const size_t off = ((size_t)slot * m->slot_stride + (size_t)layer * m->layer_stride) * m->wsize;
+    std::vector<char> kb((size_t)n * m->wsize), vb((size_t)n * m->wsize);
+    NVL_HIP(hipMemcpy(kb.data(), (char*)m->kcache + off, kb.size(), hipMemcpyDeviceToHost));
+    NVL_HIP(hipMemcpy(vb.data(), (char*)m->vcache + off, vb.size(), hipMemcpyDeviceToHost));
+    auto rd = [&](const std::vector<char>& b, int64_t i) -> float {
+        if (m->f32) return ((const float*)b.data())[i];
+        uint32_t u = ((uint32_t)((const uint16_t*)b.data())[i]) << 16;
+        float f; memcpy(&f, &u, 4); return f;
+    };
+    for (int h = 0; h < m->nKV; h++)
+        for (int t = 0; t < T; t++)
+            for (int d = 0; d < hd; d++) {
+                const int64_t o = ((int64_t)h * T + t) * hd + d;
+                if (k_out) k_out[o] = rd(kb, ((int64_t)h * Tmax + t) * hd + d);
+                if (v_out) v_out[o] = m->f32 ? rd(vb, ((int64_t)h * Tmax + t) * hd + d)
+                                             : rd(vb, ((int64_t)h * hd + d) * Tmax + t);   // bf16 path keeps V^T
+            }
+    return T;
+    NVL_CATCH(m)
+}
+
+extern "C" int nvl_set_profile(nvl_model* m, int on) {
+    if (!m) return NVL_ERR_INVALID;
+    m->profile = on != 0;
+    return NVL_OK;
+}
+extern "C" int nvl_get_stats(nvl_model* m, nvl_stats* out) {
+    if (!m || !out) return NVL_ERR_INVALID;
+    *out = m->stats;
+    return NVL_OK;
+}
+extern "C" int nvl_reset_stats(nvl_model* m) {
+    if (!m) return NVL_ERR_INVALID;
+    const double wb = m->stats.weight_bytes;
+    m->stats = nvl_stats{};
+    m->stats.weight_bytes = wb;
+    return NVL_OK;
+}
+
+// =================================================================================================
+// runner: ModelRunner.Run semantics (tensor_model_runner.go:55-97)
+// =================================================================================================
+extern "C" int nvl_runner_run(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* const* token_ptrs,
+                              const int32_t* token_lens, int is_prefill, int32_t* next_tokens, float* logits_out) {
+    if (!m) return NVL_ERR_INVALID;
+    if (!m->finalized) return fail(m, NVL_ERR_STATE, "nvl_runner_run: model not finalized");
+    if (n_seqs <= 0 || !seq_ids || !token_ptrs || !token_lens || !next_tokens)
+        return fail(m, NVL_ERR_INVALID, "nvl_runner_run: null/empty arguments");
+    // Partition: sequences that can take the 1-token decode path vs sequences that must be (re)prefilled.
+    std::vector<int> dec, pre;
+    for (int i = 0; i < n_seqs; i++) {
+        if (token_lens[i] <= 0) return fail(m, NVL_ERR_INVALID, "nvl_runner_run: sequence without tokens");
+        if (token_lens[i] > m->cfg.max_seq_len) return fail(m, NVL_ERR_POSITION, "nvl_runner_run: sequence longer than max_seq_len");
+        bool can_decode = false;
+        if (!is_prefill) {
+            auto it = m->seq_slot.find(seq_ids[i]);
+            can_decode = it != m->seq_slot.end() && m->slot_len[(size_t)it->second] == token_lens[i] - 1;
+        }
+        (can_decode ? dec : pre).push_back(i);
+    }
+    const int V = m->V;
+    // ---- decode group: one token per sequence at position len-1 (:78-80)
+    for (size_t base = 0; base < dec.size(); base += (size_t)m->opts.max_seqs) {
+        const size_t n = std::min(dec.size() - base, (size_t)m->opts.max_seqs);
+        std::vector<int64_t> ids(n); std::vector<int32_t> toks(n), lens(n, 1), pos(n), out(n);
+        for (size_t j = 0; j < n; j++) {
+            const int i = dec[base + j];
+            ids[j] = seq_ids[i]; toks[j] = token_ptrs[i][token_lens[i] - 1]; pos[j] = token_lens[i] - 1;
+        }
+        std::vector<float> lg(logits_out ? n * (size_t)V : 0);
+        const int rc = nvl_forward(m, (int)n, ids.data(), toks.data(), lens.data(), pos.data(), 0,
+                                   logits_out ? lg.data() : nullptr, out.data());
+        if (rc) return rc;
+        for (size_t j = 0; j < n; j++) {
+            next_tokens[dec[base + j]] = out[j];
+            if (logits_out) memcpy(logits_out + (size_t)dec[base + j] * V, &lg[j * (size_t)V], (size_t)V * 4);
+        }
+    }
+    // ---- prefill group: discard the cache, run the whole history from position 0 (:63-66,75);
+    // packed into forward calls of at most max_batch_tokens; a longer history is fed in chunks.
+    size_t k = 0;
+    while (k < pre.size()) {
+        std::vector<int64_t> ids; std::vector<int32_t> toks, lens, pos; std::vector<int> who;
+        int64_t budget = m->opts.max_batch_tokens;
+        while (k < pre.size() && (int)ids.size() < m->opts.max_seqs) {
+            const int i = pre[k];
+            if (token_lens[i] > budget) break;
+            int rc = nvl_seq_reset(m, seq_ids[i]);
+            if (rc) return rc;
+            ids.push_back(seq_ids[i]); lens.push_back(token_lens[i]); pos.push_back(0); who.push_back(i);
+            toks.insert(toks.end(), token_ptrs[i], token_ptrs[i] + token_lens[i]);
+            budget -= token_lens[i];
+            k++;
+        }
+        if (ids.empty()) {   // one history longer than max_batch_tokens: chunked prefill of that sequence
+            const int i = pre[k];
+            int rc = nvl_seq_reset(m, seq_ids[i]);
+            if (rc) return rc;
+            int done = 0; int32_t out = 0;
+            std::vector<float> lg(logits_out ? (size_t)V : 0);
+            while (done < token_lens[i]) {
+                const int32_t n = (int32_t)std::min<int64_t>(m->opts.max_batch_tokens, token_lens[i] - done);
+                const int32_t p0 = done;
+                rc = nvl_forward(m, 1, &seq_ids[i], token_ptrs[i] + done, &n, &p0, 0, logits_out ? lg.data() : nullptr, &out);
+                if (rc) return rc;
+                done += n;
+            }
+            next_tokens[i] = out;
+            if (logits_out) memcpy(logits_out + (size_t)i * V, lg.data(), (size_t)V * 4);
+            k++;
+            continue;
+        }
+        std::vector<int32_t> out(ids.size());
+        std::vector<float> lg(logits_out ? ids.size() * (size_t)V : 0);
+        const int rc = nvl_forward(m, (int)ids.size(), ids.data(), toks.data(), lens.data(), pos.data(), 0,
+                                   logits_out ? lg.data() : nullptr, out.data());
+        if (rc) return rc;
+        for (size_t j = 0; j < who.size(); j++) {
+            next_tokens[who[j]] = out[j];
+            if (logits_out) memcpy(logits_out + (size_t)who[j] * V, &lg[j * (size_t)V], (size_t)V * 4);
+        }
+    }
+    return NVL_OK;
+}
+
+#include "ops_impl.h"

@@ -1,0 +1,309 @@
+// ops_impl.h — op-level C-ABI entry points (nvl_op_*), included at the end of nvllm.hip.
+// Host fp32 in / host fp32 out; every one runs the SAME device kernels as the model path, on
+// one op, so tests/ can compare each reference function with the oracle in isolation.
+// (Test/diagnostic surface: allocates and frees device memory on every call.)
+#pragma once
+
+namespace {
+
+struct OpCtx {   // a model-less nvl_model carrying just a stream and the fields the helpers read
+    nvl_model m;
+    std::vector<void*> bufs;
+    OpCtx(int device, int precision) {
+        if (nvl_device_count() <= device) throw std::runtime_error("no HIP device (this library has no CPU fallback)");
+        NVL_HIP(hipSetDevice(device));
+        m.device = device;
+        m.f32 = precision == NVL_PRECISION_F32;
+        m.wsize = m.f32 ? 4 : 2;
+        NVL_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+    }
+    ~OpCtx() {
+        if (m.stream) { (void)hipStreamSynchronize(m.stream); (void)hipStreamDestroy(m.stream); }
+        for (void* p : bufs) dfree(p);
+    }
+    void* alloc(int64_t bytes) { void* p = dmalloc_bytes(bytes); bufs.push_back(p); return p; }
+    float* up_f32(const float* h, int64_t n) {
+        float* d = (float*)alloc(n * 4);
+        NVL_HIP(hipMemcpyAsync(d, h, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
+        return d;
+    }
+    // host fp32 [N][K] (or [K][N] when in_out) -> device activation/weight dtype [Npad][K]
+    void* up_mat(const float* h, int64_t N, int64_t K, bool in_out, int64_t pad_rows_to = 1) {
+        float* raw = up_f32(h, N * K);
+        const int64_t Np = round_up(N, pad_rows_to);
+        void* d = alloc(Np * K * (int64_t)m.wsize);
+        NVL_HIP(hipMemsetAsync(d, 0, (size_t)(Np * K) * m.wsize, m.stream));
+        dim3 grid((unsigned)cdiv(K, 32), (unsigned)cdiv(N, 32));
+        if (m.f32) hipLaunchKernelGGL((convert_2d_kernel<float>), grid, dim3(256), 0, m.stream, raw, 0, in_out ? 1 : 0, (float*)d, N, K);
+        else hipLaunchKernelGGL((convert_2d_kernel<bf16_t>), grid, dim3(256), 0, m.stream, raw, 0, in_out ? 1 : 0, (bf16_t*)d, N, K);
+        NVL_HIP(hipGetLastError());
+        return d;
+    }
+    void down(float* h, const void* d, int64_t n) {
+        NVL_HIP(hipMemcpyAsync(h, d, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
+        NVL_HIP(hipStreamSynchronize(m.stream));
+    }
+};
+
+int op_fail(const std::string& s, int code = NVL_ERR_INVALID) { g_create_err = s; return code; }
+
+#define OP_TRY try {
+#define OP_CATCH                                                                              \
+    } catch (const HipError& e) {                                                             \
+        return op_fail(std::string("HIP error: ") + hipGetErrorString(e.code) + " (" + e.what + ")", NVL_ERR_HIP); \
+    } catch (const std::exception& e) {                                                       \
+        const std::string w = e.what();                                                       \
+        return op_fail(w, w.find("no HIP device") != std::string::npos ? NVL_ERR_NO_DEVICE : NVL_ERR_INVALID); \
+    }
+
+}  // namespace
+
+extern "C" int nvl_op_matmul(int device, int precision, const float* a, const float* b, float* c, int M, int K, int N) {
+    if (!a || !b || !c || M <= 0 || K <= 0 || N <= 0) return op_fail("nvl_op_matmul: bad arguments");
+    if (K % 64 != 0) return op_fail("nvl_op_matmul: K must be a multiple of 64");
+    OP_TRY
+    OpCtx cx(device, precision);
+    void* A = cx.up_mat(a, M, K, false);
+    void* W = cx.up_mat(b, N, K, true, 128);
+    const int ldc = (int)round_up(N, 4);
+    float* C = (float*)cx.alloc((int64_t)M * ldc * 4);
+    gemm(&cx.m, EPI_STORE, true, mk(A, K, W, C, ldc, nullptr, 1.f, M, N, K));
+    std::vector<float> tmp((size_t)M * ldc);
+    cx.down(tmp.data(), C, (int64_t)M * ldc);
+    for (int i = 0; i < M; i++) memcpy(c + (size_t)i * N, &tmp[(size_t)i * ldc], (size_t)N * 4);
+    return NVL_OK;
+    OP_CATCH
+}
+
+extern "C" int nvl_op_layernorm(int device, const float* x, const float* w, const float* bias, float eps, float* y,
+                                int rows, int hidden) {
+    if (!x || !w || !y || rows <= 0 || hidden <= 0 || hidden % 4) return op_fail("nvl_op_layernorm: bad arguments");
+    OP_TRY
+    OpCtx cx(device, NVL_PRECISION_F32);
+    float* dx = cx.up_f32(x, (int64_t)rows * hidden);
+    float* dw = cx.up_f32(w, hidden);
+    float* db = bias ? cx.up_f32(bias, hidden) : nullptr;
+    float* dy = (float*)cx.alloc((int64_t)rows * hidden * 4);
+    hipLaunchKernelGGL((norm_kernel<float>), dim3(cdiv(rows, 4)), dim3(256), 0, cx.m.stream, dx, (const int32_t*)nullptr, dw,
+                       db, eps, dy, rows, hidden);
+    NVL_HIP(hipGetLastError());
+    cx.down(y, dy, (int64_t)rows * hidden);
+    return NVL_OK;
+    OP_CATCH
+}
+
+extern "C" int nvl_op_softmax(int device, const float* x, float* y, int rows, int cols) {
+    if (!x || !y || rows <= 0 || cols <= 0) return op_fail("nvl_op_softmax: bad arguments");
+    OP_TRY
+    OpCtx cx(device, NVL_PRECISION_F32);
+    float* dx = cx.up_f32(x, (int64_t)rows * cols);
+    float* dy = (float*)cx.alloc((int64_t)rows * cols * 4);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, cx.m.stream, dx, dy, rows, cols);
+    NVL_HIP(hipGetLastError());
+    cx.down(y, dy, (int64_t)rows * cols);
+    return NVL_OK;
+    OP_CATCH
+}
+
+static int op_unary(int device, const float* x, float* y, int64_t n, int which) {
+    if (!x || !y || n <= 0) return op_fail("nvl_op_gelu/silu: bad arguments");
+    OP_TRY
+    OpCtx cx(device, NVL_PRECISION_F32);
+    float* dx = cx.up_f32(x, n);
+    float* dy = (float*)cx.alloc(n * 4);
+    if (which == 0) hipLaunchKernelGGL(gelu_kernel, dim3(cdiv(n, 256)), dim3(256), 0, cx.m.stream, dx, dy, n);
+    else hipLaunchKernelGGL(silu_kernel, dim3(cdiv(n, 256)), dim3(256), 0, cx.m.stream, dx, dy, n);
+    NVL_HIP(hipGetLastError());
+    cx.down(y, dy, n);
+    return NVL_OK;
+    OP_CATCH
+}
+extern "C" int nvl_op_gelu(int device, const float* x, float* y, int64_t n) { return op_unary(device, x, y, n, 0); }
+extern "C" int nvl_op_silu(int device, const float* x, float* y, int64_t n) { return op_unary(device, x, y, n, 1); }
+
+// ApplyRoPESingleTensor on t [heads, seq, hd]: runs rope_kv_kernel with every head treated as a
+// query head of a one-sequence batch (the K/V branches are exercised by the model-level tests).
+extern "C" int nvl_op_rope(int device, float* t, int heads, int seq, int hd, int start_pos, double base, int max_seq) {
+    if (!t || heads <= 0 || seq <= 0 || hd <= 0 || hd % 2) return op_fail("nvl_op_rope: bad arguments");
+    if (start_pos < 0 || start_pos + seq > max_seq) return op_fail("nvl_op_rope: position exceeds max_seq", NVL_ERR_POSITION);
+    OP_TRY
+    OpCtx cx(device, NVL_PRECISION_F32);
+    const int half = hd / 2;
+    std::vector<float> ct((size_t)max_seq * hd), st((size_t)max_seq * hd);
+    for (int pos = 0; pos < max_seq; pos++)
+        for (int i = 0; i < half; i++) {
+            const double freq = 1.0 / std::pow(base, (double)(2 * i) / (double)hd);
+            const double ang = (double)pos * freq;
+            ct[(size_t)pos * hd + i] = ct[(size_t)pos * hd + half + i] = (float)std::cos(ang);
+            st[(size_t)pos * hd + i] = st[(size_t)pos * hd + half + i] = (float)std::sin(ang);
+        }
+    // [heads, seq, hd] -> token-major [seq][heads*hd]
+    std::vector<float> tm((size_t)heads * seq * hd);
+    for (int h = 0; h < heads; h++)
+        for (int s = 0; s < seq; s++)
+            memcpy(&tm[((size_t)s * heads + h) * hd], t + ((size_t)h * seq + s) * hd, (size_t)hd * 4);
+    std::vector<int32_t> pos((size_t)seq), slot((size_t)seq, 0);
+    for (int s = 0; s < seq; s++) pos[(size_t)s] = start_pos + s;
+    float* dq = cx.up_f32(tm.data(), (int64_t)tm.size());
+    float* dc = cx.up_f32(ct.data(), (int64_t)ct.size());
+    float* ds = cx.up_f32(st.data(), (int64_t)st.size());
+    int32_t* dpos = (int32_t*)cx.alloc((int64_t)seq * 4);
+    int32_t* dslot = (int32_t*)cx.alloc((int64_t)seq * 4);
+    NVL_HIP(hipMemcpyAsync(dpos, pos.data(), (size_t)seq * 4, hipMemcpyHostToDevice, cx.m.stream));
+    NVL_HIP(hipMemcpyAsync(dslot, slot.data(), (size_t)seq * 4, hipMemcpyHostToDevice, cx.m.stream));
+    float* dout = (float*)cx.alloc((int64_t)tm.size() * 4);
+    hipLaunchKernelGGL((rope_kv_kernel<float, false>), dim3(seq, heads), dim3(half), 0, cx.m.stream, dq, heads * hd, dpos, dslot,
+                       dc, ds, dout, heads * hd, (float*)nullptr, (float*)nullptr, (int64_t)0, max_seq, heads, 0, hd);
+    NVL_HIP(hipGetLastError());
+    cx.down(tm.data(), dout, (int64_t)tm.size());
+    for (int h = 0; h < heads; h++)
+        for (int s = 0; s < seq; s++)
+            memcpy(t + ((size_t)h * seq + s) * hd, &tm[((size_t)s * heads + h) * hd], (size_t)hd * 4);
+    return NVL_OK;
+    OP_CATCH
+}
+
+extern "C" int nvl_op_attention(int device, int precision, const float* q, const float* k, const float* v, int nH, int nKV,
+                                int S, int T, int hd, float scale, float* out) {
+    if (!q || !k || !v || !out || nH <= 0 || nKV <= 0 || nH % nKV || S <= 0 || T < S || (hd != 64 && hd != 128))
+        return op_fail("nvl_op_attention: bad arguments");
+    OP_TRY
+    OpCtx cx(device, precision);
+    nvl_model& m = cx.m;
+    const int Tmax = (int)round_up(T, 64);
+    if (m.f32 && Tmax > 12000) return op_fail("nvl_op_attention: T too long for the f32 kernel");
+    // token-major Q, slab-layout K, and V (bf16 path: V^T)
+    std::vector<float> qt((size_t)S * nH * hd), kc((size_t)nKV * Tmax * hd, 0.f), vc((size_t)nKV * Tmax * hd, 0.f);
+    for (int h = 0; h < nH; h++)
+        for (int s = 0; s < S; s++)
+            memcpy(&qt[((size_t)s * nH + h) * hd], q + ((size_t)h * S + s) * hd, (size_t)hd * 4);
+    for (int h = 0; h < nKV; h++)
+        for (int t = 0; t < T; t++)
+            for (int d = 0; d < hd; d++) {
+                kc[((size_t)h * Tmax + t) * hd + d] = k[((size_t)h * T + t) * hd + d];
+                if (m.f32) vc[((size_t)h * Tmax + t) * hd + d] = v[((size_t)h * T + t) * hd + d];
+                else vc[((size_t)h * hd + d) * Tmax + t] = v[((size_t)h * T + t) * hd + d];
+            }
+    m.q = cx.up_mat(qt.data(), S, (int64_t)nH * hd, false);
+    m.kcache = cx.up_mat(kc.data(), 1, (int64_t)kc.size(), false);
+    m.vcache = cx.up_mat(vc.data(), 1, (int64_t)vc.size(), false);
+    m.attn_out = cx.alloc((int64_t)S * nH * hd * (int64_t)m.wsize);
+    m.nH = nH; m.nKV = nKV; m.group = nH / nKV; m.hd = hd; m.Tmax = Tmax; m.L = 1;
+    m.layer_stride = (int64_t)nKV * Tmax * hd; m.slot_stride = m.layer_stride;
+    m.attn_scale = scale != 0.f ? scale : 1.0f / std::sqrt((float)hd);
+    const int32_t meta[4] = {0, S, T - S, 0};
+    int32_t* dmeta = (int32_t*)cx.alloc(16);
+    NVL_HIP(hipMemcpyAsync(dmeta, meta, 16, hipMemcpyHostToDevice, m.stream));
+    Meta md{};
+    md.seq_tok_start = dmeta; md.seq_len = dmeta + 1; md.seq_pos = dmeta + 2; md.seq_slot = dmeta + 3;
+    attention(&m, 0, md, 1, S, 0.0);
+    // back to fp32 [nH, S, hd]
+    std::vector<float> ot((size_t)S * nH * hd);
+    if (m.f32) {
+        cx.down(ot.data(), m.attn_out, (int64_t)ot.size());
+    } else {
+        std::vector<uint16_t> ob(ot.size());
+        NVL_HIP(hipMemcpyAsync(ob.data(), m.attn_out, ob.size() * 2, hipMemcpyDeviceToHost, m.stream));
+        NVL_HIP(hipStreamSynchronize(m.stream));
+        for (size_t i = 0; i < ob.size(); i++) { uint32_t u = ((uint32_t)ob[i]) << 16; memcpy(&ot[i], &u, 4); }
+    }
+    for (int h = 0; h < nH; h++)
+        for (int s = 0; s < S; s++)
+            memcpy(out + ((size_t)h * S + s) * hd, &ot[((size_t)s * nH + h) * hd], (size_t)hd * 4);
+    m.q = m.kcache = m.vcache = m.attn_out = nullptr;   // owned by cx.bufs
+    return NVL_OK;
+    OP_CATCH
+}
+
+extern "C" int nvl_op_ffn(int device, int precision, const float* x, const float* w1, const float* b1, const float* w2,
+                          const float* b2, int rows, int hidden, int ffn, int swiglu, float* y) {
+    if (!x || !w1 || !w2 || !y || rows <= 0 || hidden % 64 || ffn % 64) return op_fail("nvl_op_ffn: bad arguments");
+    OP_TRY
+    OpCtx cx(device, precision);
+    nvl_model& m = cx.m;
+    m.H = hidden; m.F = ffn;
+    m.cfg.activation_type = swiglu ? NVL_ACT_SWIGLU : NVL_ACT_GELU;
+    m.xn = cx.up_mat(x, rows, hidden, false);
+    LayerW l;
+    const int n1 = swiglu ? 2 * ffn : ffn;
+    void* w1c = cx.up_mat(w1, n1, hidden, true, 128);   // canonical [n1][H] (gate rows | up rows)
+    if (swiglu && !m.f32) {
+        auto idx = swiglu_interleave(ffn, 0);
+        idx.resize((size_t)round_up(n1, 128), -1);
+        l.w1 = cx.alloc((int64_t)idx.size() * hidden * 2);
+        gather_rows(&m, w1c, idx, l.w1, hidden);
+    } else {
+        l.w1 = w1c;
+    }
+    if (b1) l.t[NVL_T_B1].p = cx.up_f32(b1, ffn);
+    void* w2d = cx.up_mat(w2, hidden, ffn, true, 128);
+    float* b2d = b2 ? cx.up_f32(b2, hidden) : nullptr;
+    m.hbuf = cx.alloc((int64_t)rows * ffn * (int64_t)m.wsize);
+    if (m.f32 && swiglu) m.h2 = (float*)cx.alloc((int64_t)rows * 2 * ffn * 4);
+    ffn_up(&m, l, rows);
+    float* yd = (float*)cx.alloc((int64_t)rows * hidden * 4);
+    gemm(&m, EPI_STORE, true, mk(m.hbuf, ffn, w2d, yd, hidden, b2d, 1.f, rows, hidden, ffn));
+    cx.down(y, yd, (int64_t)rows * hidden);
+    l.w1 = nullptr; l.t[NVL_T_B1].p = nullptr;
+    m.xn = m.hbuf = nullptr; m.h2 = nullptr;
+    return NVL_OK;
+    OP_CATCH
+}
+
+extern "C" int nvl_op_moe(int device, int precision, const float* x, const float* router, const float* w_in,
+                          const float* w_out, int rows, int hidden, int n_experts, int top_k, int inter, float* y) {
+    if (!x || !router || !w_in || !w_out || !y || rows <= 0 || hidden % 64 || inter % 64 || n_experts > 64 || top_k > n_experts)
+        return op_fail("nvl_op_moe: bad arguments");
+    OP_TRY
+    OpCtx cx(device, precision);
+    nvl_model& m = cx.m;
+    m.H = hidden; m.F = inter;
+    m.cfg.num_experts = n_experts; m.cfg.num_experts_per_tok = top_k; m.cfg.use_moe = 1; m.cfg.residual_multiplier = 0.f;
+    m.xn = cx.up_mat(x, rows, hidden, false);
+    LayerW l;
+    l.t[NVL_T_ROUTER].p = cx.up_mat(router, n_experts, hidden, true, 128);
+    void* inc = cx.up_mat(w_in, (int64_t)n_experts * 2 * inter, hidden, false);
+    if (!m.f32) {
+        std::vector<int32_t> idx;
+        for (int e = 0; e < n_experts; e++) {
+            auto one = swiglu_interleave(inter, (int64_t)e * 2 * inter);
+            idx.insert(idx.end(), one.begin(), one.end());
+        }
+        l.moe_in = cx.alloc((int64_t)idx.size() * hidden * 2);
+        gather_rows(&m, inc, idx, l.moe_in, hidden);
+    } else {
+        l.moe_in = inc;
+    }
+    l.t[NVL_T_MOE_OUT].p = cx.up_mat(w_out, (int64_t)n_experts * hidden, inter, false);
+    const int64_t pairs = (int64_t)rows * top_k;
+    m.router_logits = (float*)cx.alloc((int64_t)rows * 128 * 4);
+    m.expert_ids = (int32_t*)cx.alloc(pairs * 4); m.expert_w = (float*)cx.alloc(pairs * 4);
+    m.seg_start = (int32_t*)cx.alloc((n_experts + 1) * 4);
+    m.perm_token = (int32_t*)cx.alloc(pairs * 4); m.slot_of = (int32_t*)cx.alloc(pairs * 4);
+    m.moe_eo = (float*)cx.alloc(pairs * hidden * 4);
+    m.hbuf = cx.alloc(pairs * inter * (int64_t)m.wsize);
+    if (m.f32) m.h2 = (float*)cx.alloc(pairs * 2 * inter * 4);
+    m.x = (float*)cx.alloc((int64_t)rows * hidden * 4);
+    NVL_HIP(hipMemsetAsync(m.x, 0, (size_t)rows * hidden * 4, m.stream));
+    moe(&m, l, rows);    // accumulates into x (zeroed) with multiplier 1
+    cx.down(y, m.x, (int64_t)rows * hidden);
+    l.moe_in = nullptr; l.t[NVL_T_ROUTER].p = nullptr; l.t[NVL_T_MOE_OUT].p = nullptr;
+    m.xn = m.hbuf = nullptr; m.h2 = nullptr; m.x = nullptr; m.router_logits = nullptr; m.expert_ids = nullptr;
+    m.expert_w = nullptr; m.seg_start = m.perm_token = m.slot_of = nullptr; m.moe_eo = nullptr;
+    return NVL_OK;
+    OP_CATCH
+}
+
+extern "C" int nvl_op_argmax(int device, const float* x, int rows, int cols, int32_t* out) {
+    if (!x || !out || rows <= 0 || cols <= 0) return op_fail("nvl_op_argmax: bad arguments");
+    OP_TRY
+    OpCtx cx(device, NVL_PRECISION_F32);
+    float* dx = cx.up_f32(x, (int64_t)rows * cols);
+    int32_t* d = (int32_t*)cx.alloc((int64_t)rows * 4);
+    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, cx.m.stream, dx, cols, cols, 0.f, d);
+    NVL_HIP(hipGetLastError());
+    NVL_HIP(hipMemcpyAsync(out, d, (size_t)rows * 4, hipMemcpyDeviceToHost, cx.m.stream));
+    NVL_HIP(hipStreamSynchronize(cx.m.stream));
+    return NVL_OK;
+    OP_CATCH
+}

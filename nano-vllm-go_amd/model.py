@@ -1,0 +1,183 @@
+"""Host-side mirror of tensor.TransformerModel (purego/tensor/generic_model.go:4-19) over the C ABI:
+same method names and argument meaning as the reference (ForwardWithCache, GetLogitsForLastToken),
+device-resident weights and KV slabs underneath."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _cfg_struct(cfg: dict) -> L.ModelConfigC:
+    c = L.ModelConfigC()
+    for k in ("vocab_size", "hidden", "num_layers", "num_heads", "num_kv_heads", "head_dim", "ffn_dim",
+              "max_seq_len", "num_experts", "num_experts_per_tok"):
+        setattr(c, k, int(cfg.get(k, 0)))
+    c.attention_type = L.ATTN[cfg["attention_type"]]
+    c.norm_type = L.NORM[cfg["norm_type"]]
+    c.position_type = L.POS[cfg["position_type"]]
+    c.activation_type = L.ACT[cfg["activation_type"]]
+    c.block_style = L.BLOCK[cfg["block_style"]]
+    c.rope_base = float(cfg.get("rope_base", 10000.0))
+    c.norm_eps = float(cfg.get("norm_eps", 1e-5))
+    c.tied_embedding = int(bool(cfg.get("tied_embedding", False)))
+    c.use_moe = int(bool(cfg.get("use_moe", False)))
+    for k in ("embedding_multiplier", "attention_multiplier", "residual_multiplier", "logits_scaling"):
+        setattr(c, k, float(cfg.get(k, 0.0)))
+    return c
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class HipTransformerModel:
+    """tensor.TransformerModel on one MI355X.  `tensors` is {(slot, layer): array} in the reference's
+    post-load layout (2-D weights [in, out]); arrays may be numpy fp32 or torch tensors (fp32/bf16,
+    host or device) — torch device tensors are handed over by pointer with no host copy."""
+
+    def __init__(self, cfg: dict, tensors: dict, *, device: int = 0, precision: str = "bf16",
+                 max_seqs: int = 8, max_batch_tokens: int | None = None):
+        self.cfg = dict(cfg)
+        self.lib = L.lib()
+        self.h = C.c_void_p()
+        opts = L.RuntimeOptsC(device=device, precision=L.PRECISION[precision], max_seqs=max_seqs,
+                              max_batch_tokens=max_batch_tokens or cfg["max_seq_len"], tp_rank=0, tp_size=1)
+        self._c = _cfg_struct(cfg)
+        L.check(self.lib.nvl_create(C.byref(self._c), C.byref(opts), C.byref(self.h)))
+        for (slot, layer), arr in tensors.items():
+            self.upload(slot, layer, arr)
+        L.check(self.lib.nvl_finalize(self.h), self.h)
+        self.V = cfg["vocab_size"]
+        self.H = cfg["hidden"]
+
+    # -- weights -----------------------------------------------------------------------------
+    def upload(self, slot: str, layer: int, arr, layout: int = L.LAYOUT_IN_OUT):
+        ptr, dtype, shape, keep = _as_pointer(arr)
+        if slot in L.ONE_D:
+            rows, cols = int(np.prod(shape)), 1
+        elif slot in ("moe_in", "moe_out"):
+            rows, cols = shape[0] * shape[1], shape[2]
+        else:
+            rows, cols = shape
+        L.check(self.lib.nvl_upload_tensor(self.h, L.SLOT_ID[slot], int(layer), ptr, dtype, rows, cols, layout), self.h)
+        del keep
+
+    # -- sequences (replace kvCaches map[int64]*KVCache, tensor_model_runner.go:13) ----------------
+    def seq_reset(self, seq_id: int):
+        L.check(self.lib.nvl_seq_reset(self.h, seq_id), self.h)
+
+    def seq_close(self, seq_id: int):
+        L.check(self.lib.nvl_seq_close(self.h, seq_id), self.h)
+
+    def seq_close_all(self):
+        L.check(self.lib.nvl_seq_close_all(self.h), self.h)
+
+    def seq_len(self, seq_id: int) -> int:
+        return self.lib.nvl_seq_len(self.h, seq_id)
+
+    # -- forward --------------------------------------------------------------------------------
+    def forward_batch(self, seq_ids, token_lists, pos_offsets, *, all_logits=False, want_logits=True):
+        """nvl_forward: returns (logits [rows, V] or None, argmax [n_seqs])."""
+        n = len(seq_ids)
+        ids = np.asarray(seq_ids, np.int64)
+        lens = np.asarray([len(t) for t in token_lists], np.int32)
+        toks = np.concatenate([np.asarray(t, np.int32) for t in token_lists]).astype(np.int32)
+        pos = np.asarray(pos_offsets, np.int32)
+        rows = int(lens.sum()) if all_logits else n
+        logits = np.empty((rows, self.V), np.float32) if want_logits else None
+        am = np.empty(n, np.int32)
+        L.check(self.lib.nvl_forward(self.h, n, _ptr(ids), _ptr(toks), _ptr(lens), _ptr(pos),
+                                     L.FWD_ALL_LOGITS if all_logits else 0, _ptr(logits), _ptr(am)), self.h)
+        return logits, am
+
+    def forward_with_cache(self, token_ids, seq_id: int, pos_offset: int, *, all_logits=True):
+        """TransformerModel.ForwardWithCache (generic_model.go:276): logits [S, V] for one sequence.
+        The *KVCache argument of the reference is the sequence's device slot, named by seq_id;
+        pos_offset == 0 with a fresh id (or after seq_reset) is the reference's kvCache == nil."""
+        if self.seq_len(seq_id) < 0:
+            L.check(self.lib.nvl_seq_open(self.h, seq_id), self.h)
+        logits, _ = self.forward_batch([seq_id], [list(token_ids)], [pos_offset], all_logits=all_logits)
+        return logits
+
+    @staticmethod
+    def get_logits_for_last_token(logits):
+        """GetLogitsForLastToken (generic_model.go:595-604)."""
+        return logits[-1].copy()
+
+    def greedy(self, prompt, max_tokens: int, seq_id: int = 0):
+        """cmd/ask/main.go:287-360 generateResponse with argmax on the device (no EOS stop)."""
+        self.seq_reset(seq_id)
+        all_tokens = list(prompt)
+        _, am = self.forward_batch([seq_id], [all_tokens], [0], want_logits=False)
+        out = [int(am[0])]
+        all_tokens.append(out[-1])
+        for _ in range(max_tokens - 1):
+            _, am = self.forward_batch([seq_id], [[all_tokens[-1]]], [len(all_tokens) - 1], want_logits=False)
+            out.append(int(am[0]))
+            all_tokens.append(out[-1])
+        return out
+
+    # -- debug / parity taps ------------------------------------------------------------------------
+    def set_debug(self, keep_hidden: bool):
+        L.check(self.lib.nvl_set_debug(self.h, int(keep_hidden)), self.h)
+
+    def get_hidden(self, n_tokens: int):
+        out = np.empty((self.cfg["num_layers"], n_tokens, self.H), np.float32)
+        for li in range(self.cfg["num_layers"]):
+            L.check(self.lib.nvl_get_hidden(self.h, li, _ptr(out[li]), n_tokens * self.H), self.h)
+        return out
+
+    def get_kv(self, seq_id: int, layer: int):
+        T = self.seq_len(seq_id)
+        at = self.cfg["attention_type"]
+        nkv = self.cfg["num_heads"] if at == "mha" else (1 if at == "mqa" else self.cfg["num_kv_heads"])
+        k = np.empty((nkv, T, self.cfg["head_dim"]), np.float32)
+        v = np.empty_like(k)
+        L.check(self.lib.nvl_get_kv(self.h, seq_id, layer, _ptr(k), _ptr(v)), self.h)
+        return k, v
+
+    # -- measurement -------------------------------------------------------------------------------
+    def set_profile(self, on: bool):
+        L.check(self.lib.nvl_set_profile(self.h, int(on)), self.h)
+
+    def stats(self) -> dict:
+        s = L.StatsC()
+        L.check(self.lib.nvl_get_stats(self.h, C.byref(s)), self.h)
+        return {k: getattr(s, k) for k, _ in L.StatsC._fields_}
+
+    def reset_stats(self):
+        L.check(self.lib.nvl_reset_stats(self.h), self.h)
+
+    def close(self):
+        if self.h:
+            self.lib.nvl_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _as_pointer(arr):
+    """(pointer, nvl dtype, shape, keepalive) for numpy arrays or torch tensors."""
+    if isinstance(arr, np.ndarray):
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        return a.ctypes.data_as(C.c_void_p), L.DTYPE_F32, a.shape, a
+    import torch  # plumbing only: device memory handed over by pointer
+    t = arr.contiguous()
+    if t.dtype == torch.float32:
+        dt = L.DTYPE_F32
+    elif t.dtype == torch.bfloat16:
+        dt = L.DTYPE_BF16
+    elif t.dtype == torch.float16:
+        dt = L.DTYPE_F16
+    else:
+        raise TypeError(t.dtype)
+    if t.is_cuda:
+        torch.cuda.synchronize(t.device)
+    return C.c_void_p(t.data_ptr()), dt, tuple(t.shape), t

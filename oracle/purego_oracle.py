@@ -1,0 +1,338 @@
+"""ctypes binding of oracle/purego_oracle.c — the CPU restatement of nano-vllm-go's
+purego/tensor forward path.
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never from the product package (nano-vllm-go_amd/).  PARITY UNPINNED for
+arithmetic (see purego_oracle.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_SO = _HERE / "_build" / "libpurego_oracle.so"
+
+SLOTS = [
+    "tok_emb", "pos_emb", "lm_head", "final_norm_w", "final_norm_b",
+    "attn_norm_w", "attn_norm_b", "ffn_norm_w", "ffn_norm_b",
+    "wq", "wk", "wv", "wkv", "wo", "bq", "bk", "bv", "bo",
+    "w1", "b1", "w2", "b2", "router", "moe_in", "moe_out",
+]
+SLOT_ID = {n: i for i, n in enumerate(SLOTS)}
+GLOBAL_SLOTS = set(SLOTS[:5])
+
+ATTN = {"mha": 0, "mqa": 1, "gqa": 2}
+NORM = {"layernorm": 0, "rmsnorm": 1}
+POS = {"learned": 0, "rope": 1, "nope": 2}
+ACT = {"gelu": 0, "swiglu": 1}
+BLOCK = {"sequential": 0, "parallel": 1}
+
+
+class PoConfig(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_int32), ("hidden", C.c_int32), ("num_layers", C.c_int32),
+        ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32), ("head_dim", C.c_int32),
+        ("ffn_dim", C.c_int32), ("max_seq_len", C.c_int32),
+        ("attention_type", C.c_int32), ("norm_type", C.c_int32), ("position_type", C.c_int32),
+        ("activation_type", C.c_int32), ("block_style", C.c_int32),
+        ("rope_base", C.c_double), ("norm_eps", C.c_float), ("tied_embedding", C.c_int32),
+        ("use_moe", C.c_int32), ("num_experts", C.c_int32), ("num_experts_per_tok", C.c_int32),
+        ("embedding_multiplier", C.c_float), ("attention_multiplier", C.c_float),
+        ("residual_multiplier", C.c_float), ("logits_scaling", C.c_float),
+    ]
+
+
+def build(force: bool = False) -> Path:
+    src = [_HERE / "purego_oracle.c", _HERE / "purego_oracle.h"]
+    if force or not _SO.exists() or any(s.stat().st_mtime > _SO.stat().st_mtime for s in src):
+        subprocess.check_call(["make", "-C", str(_HERE), "-s"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+fp = C.POINTER(C.c_float)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(str(_SO))
+        L.po_model_new.restype = C.c_void_p
+        L.po_model_new.argtypes = [C.POINTER(PoConfig)]
+        L.po_model_free.argtypes = [C.c_void_p]
+        L.po_model_set.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+        L.po_model_set_borrowed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+        L.po_kvcache_new.restype = C.c_void_p
+        L.po_kvcache_new.argtypes = [C.c_int]
+        L.po_kvcache_free.argtypes = [C.c_void_p]
+        L.po_kvcache_len.argtypes = [C.c_void_p]
+        L.po_kvcache_get.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.po_forward_with_cache.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_void_p]
+        L.po_argmax.argtypes = [C.c_void_p, C.c_int]
+        L.po_matmul.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3
+        L.po_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int]
+        L.po_softmax_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.po_gelu.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.po_silu.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.po_rope_tables.argtypes = [C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        L.po_rope_apply.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.po_ffn.argtypes = [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]
+        L.po_gqa_core.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_float, C.c_void_p]
+        L.po_moe.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]
+        L.po_transpose.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.po_split_gpt2_qkv.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.po_split_falcon_qkv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.po_combine_mqa_kv.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.po_concat_last_dim.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.po_f32_from_bf16.restype = C.c_float
+        L.po_f32_from_bf16.argtypes = [C.c_uint16]
+        L.po_f32_from_f16.restype = C.c_float
+        L.po_f32_from_f16.argtypes = [C.c_uint16]
+        _lib = L
+    return _lib
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def make_config(cfg: dict) -> PoConfig:
+    """cfg uses the field names of tensor.ModelConfig in snake case (see nano-vllm-go_amd/config.py)."""
+    c = PoConfig()
+    for k in ("vocab_size", "hidden", "num_layers", "num_heads", "num_kv_heads", "head_dim", "ffn_dim",
+              "max_seq_len", "num_experts", "num_experts_per_tok"):
+        setattr(c, k, int(cfg.get(k, 0)))
+    c.attention_type = ATTN[cfg["attention_type"]]
+    c.norm_type = NORM[cfg["norm_type"]]
+    c.position_type = POS[cfg["position_type"]]
+    c.activation_type = ACT[cfg["activation_type"]]
+    c.block_style = BLOCK[cfg["block_style"]]
+    c.rope_base = float(cfg.get("rope_base", 10000.0))
+    c.norm_eps = float(cfg.get("norm_eps", 1e-5))
+    c.tied_embedding = int(bool(cfg.get("tied_embedding", False)))
+    c.use_moe = int(bool(cfg.get("use_moe", False)))
+    for k in ("embedding_multiplier", "attention_multiplier", "residual_multiplier", "logits_scaling"):
+        setattr(c, k, float(cfg.get(k, 0.0)))
+    return c
+
+
+class KVCache:
+    def __init__(self, num_layers: int):
+        self.h = lib().po_kvcache_new(num_layers)
+
+    def __len__(self):
+        return lib().po_kvcache_len(self.h)
+
+    def layer(self, layer: int, heads: int, hd: int):
+        T = lib().po_kvcache_get(self.h, layer, 0, None)
+        k = np.empty((heads, T, hd), np.float32)
+        v = np.empty((heads, T, hd), np.float32)
+        lib().po_kvcache_get(self.h, layer, 0, _p(k))
+        lib().po_kvcache_get(self.h, layer, 1, _p(v))
+        return k, v
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().po_kvcache_free(self.h)
+            self.h = None
+
+
+class OracleModel:
+    """tensor.TransformerModel restated; weights are given in the reference's post-load layout
+    ({(slot, layer): ndarray}, 2-D weights [in, out]) — see nano-vllm-go_amd/synth.py."""
+
+    def __init__(self, cfg: dict, tensors: dict, borrow: bool = True):
+        self.cfg = cfg
+        self._c = make_config(cfg)
+        self.h = lib().po_model_new(C.byref(self._c))
+        self._keep = []
+        tensors = dict(tensors)
+        if ("lm_head", 0) not in tensors:
+            # tied (or absent) LM head = Transpose(TokenEmbedding), generic_loader.go:255-259
+            tensors[("lm_head", 0)] = transpose(tensors[("tok_emb", 0)])
+        for (slot, layer), arr in tensors.items():
+            a = _f32(arr)
+            if borrow:
+                self._keep.append(a)
+                rc = lib().po_model_set_borrowed(self.h, SLOT_ID[slot], int(layer), _p(a), a.size)
+            else:
+                rc = lib().po_model_set(self.h, SLOT_ID[slot], int(layer), _p(a), a.size)
+            assert rc == 0, (slot, layer)
+
+    def new_cache(self) -> KVCache:
+        return KVCache(self.cfg["num_layers"])
+
+    def forward_with_cache(self, tokens, kv: KVCache, pos_offset: int, want_hidden: bool = False):
+        toks = np.ascontiguousarray(tokens, dtype=np.int32)
+        S = toks.size
+        logits = np.empty((S, self.cfg["vocab_size"]), np.float32)
+        hidden = np.empty((self.cfg["num_layers"], S, self.cfg["hidden"]), np.float32) if want_hidden else None
+        rc = lib().po_forward_with_cache(self.h, _p(toks), S, kv.h, int(pos_offset), _p(logits), _p(hidden))
+        if rc != 0:
+            raise RuntimeError("oracle: the reference panics on this input (position or token out of range)")
+        return (logits, hidden) if want_hidden else logits
+
+    def greedy(self, prompt, max_tokens: int, return_margins: bool = False):
+        """cmd/ask/main.go:287-360 generateResponse with argmax, no EOS stop (ignore_eos).
+        With return_margins also returns, per step, (top1 - top2) / max|logit| of the oracle."""
+        kv = self.new_cache()
+        all_tokens = list(prompt)
+        out, margins = [], []
+
+        def step(logits):
+            row = logits[-1]
+            nxt = argmax(row)
+            top2 = np.partition(row, -2)[-2:]
+            margins.append(float((top2[1] - top2[0]) / (np.abs(row).max() + 1e-30)))
+            out.append(nxt)
+            all_tokens.append(nxt)
+
+        step(self.forward_with_cache(all_tokens, kv, 0))
+        for _ in range(max_tokens - 1):
+            step(self.forward_with_cache([all_tokens[-1]], kv, len(all_tokens) - 1))
+        return (out, margins) if return_margins else out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().po_model_free(self.h)
+            self.h = None
+
+
+# ---- op-level wrappers --------------------------------------------------------------------
+def argmax(x) -> int:
+    a = _f32(x)
+    return int(lib().po_argmax(_p(a), a.size))
+
+
+def matmul(a, b):
+    a, b = _f32(a), _f32(b)
+    m, k = a.shape
+    k2, n = b.shape
+    assert k == k2
+    c = np.empty((m, n), np.float32)
+    lib().po_matmul(_p(a), _p(b), _p(c), m, k, n)
+    return c
+
+
+def layernorm(x, w, bias, eps):
+    x, w = _f32(x), _f32(w)
+    b = None if bias is None else _f32(bias)
+    y = np.empty_like(x)
+    lib().po_layernorm(_p(x), _p(w), _p(b), eps, _p(y), x.shape[0], x.shape[1])
+    return y
+
+
+def softmax(x):
+    x = _f32(x)
+    y = np.empty_like(x)
+    lib().po_softmax_rows(_p(x), _p(y), x.shape[0], x.shape[1])
+    return y
+
+
+def gelu(x):
+    x = _f32(x)
+    y = np.empty_like(x)
+    lib().po_gelu(_p(x), _p(y), x.size)
+    return y
+
+
+def silu(x):
+    x = _f32(x)
+    y = np.empty_like(x)
+    lib().po_silu(_p(x), _p(y), x.size)
+    return y
+
+
+def rope_tables(hd, max_seq, base):
+    c = np.empty((max_seq, hd), np.float32)
+    s = np.empty((max_seq, hd), np.float32)
+    lib().po_rope_tables(hd, max_seq, base, _p(c), _p(s))
+    return c, s
+
+
+def rope_apply(t, start_pos, base, max_seq):
+    t = _f32(t).copy()
+    heads, seq, hd = t.shape
+    c, s = rope_tables(hd, max_seq, base)
+    rc = lib().po_rope_apply(_p(t), heads, seq, hd, start_pos, _p(c), _p(s), max_seq)
+    if rc != 0:
+        raise RuntimeError("oracle: position exceeds max sequence length (rope.go:176)")
+    return t
+
+
+def ffn(x, w1, b1, w2, b2, swiglu):
+    x, w1, w2 = _f32(x), _f32(w1), _f32(w2)
+    b1 = None if b1 is None else _f32(b1)
+    b2 = None if b2 is None else _f32(b2)
+    rows, hidden = x.shape
+    f = w2.shape[0]
+    y = np.empty((rows, hidden), np.float32)
+    lib().po_ffn(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), rows, hidden, f, int(swiglu), _p(y))
+    return y
+
+
+def gqa_core(q, k, v, scale=0.0):
+    q, k, v = _f32(q), _f32(k), _f32(v)
+    nH, S, hd = q.shape
+    nKV, T, _ = k.shape
+    out = np.empty_like(q)
+    lib().po_gqa_core(_p(q), _p(k), _p(v), nH, nKV, S, T, hd, scale, _p(out))
+    return out
+
+
+def moe(x, router, w_in, w_out, top_k):
+    x, router, w_in, w_out = _f32(x), _f32(router), _f32(w_in), _f32(w_out)
+    rows, hidden = x.shape
+    E = router.shape[1]
+    inter = w_out.shape[2]
+    y = np.empty((rows, hidden), np.float32)
+    lib().po_moe(_p(x), _p(router), _p(w_in), _p(w_out), rows, hidden, E, top_k, inter, _p(y))
+    return y
+
+
+def transpose(t):
+    t = _f32(t)
+    out = np.empty((t.shape[1], t.shape[0]), np.float32)
+    lib().po_transpose(_p(t), _p(out), t.shape[0], t.shape[1])
+    return out
+
+
+def split_gpt2_qkv(qkv, hidden):
+    qkv = _f32(qkv)
+    q, k, v = (np.empty((hidden, hidden), np.float32) for _ in range(3))
+    lib().po_split_gpt2_qkv(_p(qkv), hidden, _p(q), _p(k), _p(v))
+    return q, k, v
+
+
+def split_falcon_qkv(qkv, hidden, num_heads, head_dim):
+    qkv = _f32(qkv)
+    q = np.empty((hidden, num_heads * head_dim), np.float32)
+    k = np.empty((hidden, head_dim), np.float32)
+    v = np.empty((hidden, head_dim), np.float32)
+    lib().po_split_falcon_qkv(_p(qkv), hidden, num_heads, head_dim, _p(q), _p(k), _p(v))
+    return q, k, v
+
+
+def combine_mqa_kv(k, v):
+    k, v = _f32(k), _f32(v)
+    out = np.empty((k.shape[0], 2 * k.shape[1]), np.float32)
+    lib().po_combine_mqa_kv(_p(k), _p(v), k.shape[0], k.shape[1], _p(out))
+    return out
+
+
+def concat_last_dim(a, b):
+    a, b = _f32(a), _f32(b)
+    out = np.empty((a.shape[0], a.shape[1] + b.shape[1]), np.float32)
+    lib().po_concat_last_dim(_p(a), _p(b), a.shape[0], a.shape[1], b.shape[1], _p(out))
+    return out

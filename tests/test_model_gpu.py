@@ -1,0 +1,166 @@
+"""End-to-end parity of the HIP forward path (through nvl_forward / nvl_runner_run) against the CPU
+oracle on seeded tiny models of all four families, in both precisions.
+
+Stated tolerances (relative to the largest |logit| / |hidden| of the oracle):
+  f32 mode : logits and every layer's residual stream within 1e-4; greedy token ids identical
+  bf16 mode: logits within 1.5e-2, residual stream within 1.5e-2;  greedy token ids identical on
+             fixture prompts whose oracle top-2 margins exceed 2x that tolerance
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+FAMILIES = ["llama", "gpt2", "falcon", "granite_moe"]
+TOL = {"f32": 1e-4, "bf16": 1.5e-2}
+
+
+def build(gpu, oracle, family, precision, peaked=0.0, **over):
+    cfg = gpu.synth.tiny_config(family, **over)
+    w = gpu.synth.make_weights(cfg, seed=7, scale=0.05, peaked_head=peaked)
+    om = oracle.OracleModel(cfg, w)
+    hm = gpu.HipTransformerModel(cfg, w, precision=precision, max_seqs=4, max_batch_tokens=256)
+    return cfg, om, hm
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_prefill_logits_hidden_and_kv(gpu, oracle, family, precision):
+    cfg, om, hm = build(gpu, oracle, family, precision)
+    toks = np.random.default_rng(1).integers(0, cfg["vocab_size"], 37).tolist()
+    kv = om.new_cache()
+    want, want_h = om.forward_with_cache(toks, kv, 0, want_hidden=True)
+    hm.set_debug(True)
+    got = hm.forward_with_cache(toks, seq_id=5, pos_offset=0)
+    got_h = hm.get_hidden(len(toks))
+    tol = TOL[precision]
+    for li in range(cfg["num_layers"]):
+        assert rel_err(got_h[li], want_h[li]) <= tol, f"layer {li}"
+    assert rel_err(got, want) <= tol
+    # the KV the device holds is the KV the reference would hold (kv_cache.go:5-6)
+    at = cfg["attention_type"]
+    nkv = cfg["num_heads"] if at == "mha" else (1 if at == "mqa" else cfg["num_kv_heads"])
+    for li in range(cfg["num_layers"]):
+        k_ref, v_ref = kv.layer(li, nkv, cfg["head_dim"])
+        k_dev, v_dev = hm.get_kv(5, li)
+        assert rel_err(k_dev, k_ref) <= tol and rel_err(v_dev, v_ref) <= tol
+    hm.close()
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_decode_steps_match_oracle(gpu, oracle, family, precision):
+    """prefill then token-by-token decode with teacher forcing: the logits of every step match."""
+    cfg, om, hm = build(gpu, oracle, family, precision)
+    r = np.random.default_rng(2)
+    prompt = r.integers(0, cfg["vocab_size"], 19).tolist()
+    forced = r.integers(0, cfg["vocab_size"], 6).tolist()
+    kv = om.new_cache()
+    want = om.forward_with_cache(prompt, kv, 0)[-1]
+    got = hm.forward_with_cache(prompt, seq_id=1, pos_offset=0, all_logits=False)[-1]
+    assert rel_err(got, want) <= TOL[precision]
+    pos = len(prompt)
+    for t in forced:
+        want = om.forward_with_cache([t], kv, pos)[-1]
+        got = hm.forward_with_cache([t], seq_id=1, pos_offset=pos, all_logits=False)[-1]
+        assert rel_err(got, want) <= TOL[precision], f"decode pos {pos}"
+        pos += 1
+    hm.close()
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_greedy_token_ids_bit_exact(gpu, oracle, family, precision):
+    """cmd/ask's generateResponse loop (main.go:287-360) with argmax: identical token ids.
+    A random-weight model has tiny top-2 margins, so the fixture prompt is the first seeded prompt
+    whose ORACLE margins (top1-top2 over max|logit|) all exceed 2x the stated logits tolerance (the
+    reference itself is not reproducible below that: arm64 fuses FMAs, amd64 does not — SURVEY.md §7)."""
+    cfg, om, hm = build(gpu, oracle, family, precision, peaked=4.0, tied_embedding=False)
+    need = 2 * TOL[precision]
+    for seed in range(600):
+        prompt = np.random.default_rng(100 + seed).integers(0, cfg["vocab_size"], 12).tolist()
+        want, margins = om.greedy(prompt, 10, return_margins=True)
+        if min(margins) > need and len(set(want)) > 3:
+            break
+    else:
+        pytest.fail("no fixture prompt with safe margins")
+    got = hm.greedy(prompt, 10)
+    assert got == want
+    hm.close()
+
+
+def test_chunked_prefill_equals_one_shot(gpu, oracle):
+    """ForwardWithCache with S>1 at pos_offset>0 (cache + new block): same logits as one shot."""
+    cfg, om, hm = build(gpu, oracle, "llama", "f32")
+    toks = np.random.default_rng(4).integers(0, cfg["vocab_size"], 50).tolist()
+    kv = om.new_cache()
+    om.forward_with_cache(toks[:30], kv, 0)
+    want = om.forward_with_cache(toks[30:], kv, 30)
+    hm.forward_with_cache(toks[:30], seq_id=2, pos_offset=0)
+    got = hm.forward_with_cache(toks[30:], seq_id=2, pos_offset=30)
+    assert rel_err(got, want) <= TOL["f32"]
+    hm.close()
+
+
+def test_batched_forward_equals_serial(gpu, oracle):
+    """One nvl_forward over a ragged batch == the reference's serial loop (tensor_model_runner.go:58)."""
+    cfg, om, hm = build(gpu, oracle, "llama", "bf16")
+    r = np.random.default_rng(5)
+    prompts = [r.integers(0, cfg["vocab_size"], n).tolist() for n in (3, 64, 17, 1)]
+    for i in range(4):
+        hm.seq_reset(i)
+    logits, am = hm.forward_batch([0, 1, 2, 3], prompts, [0, 0, 0, 0])
+    for i, p in enumerate(prompts):
+        want = om.forward_with_cache(p, om.new_cache(), 0)[-1]
+        assert rel_err(logits[i], want) <= TOL["bf16"]
+    hm.close()
+
+
+def test_runner_semantics(gpu, oracle):
+    """TensorModelRunner.Run (tensor_model_runner.go:55-97): prefill discards the cache, decode uses the
+    last token at len-1, an unknown/stale sequence is transparently re-prefilled, ClearCache works."""
+    cfg, om, hm = build(gpu, oracle, "llama", "f32", peaked=4.0, tied_embedding=False)
+    runner = gpu.HipModelRunner(hm)
+    r = np.random.default_rng(6)
+    seqs = [gpu.Sequence(seq_id=100 + i, token_ids=r.integers(0, cfg["vocab_size"], n).tolist())
+            for i, n in enumerate((5, 9, 2))]
+    want = [om.greedy(s.token_ids, 5) for s in seqs]
+    got = [[] for _ in seqs]
+    toks = runner.run(seqs, True)
+    for step in range(5):
+        for i, s in enumerate(seqs):
+            got[i].append(toks[i])
+            s.append_token(toks[i])
+        if step == 1:
+            runner.clear_cache(seqs[1].seq_id)       # forces the re-prefill path for that sequence
+        if step < 4:
+            toks = runner.run(seqs, False)
+    assert got == want
+    # pre-emption recovery: prefill again with prompt+generated (scheduler.go:115-119)
+    toks2, logits = runner.run(seqs, True, return_logits=True)
+    for i, s in enumerate(seqs):
+        ref = om.forward_with_cache(s.token_ids, om.new_cache(), 0)[-1]
+        assert rel_err(logits[i], ref) <= TOL["f32"]
+        assert toks2[i] == oracle.argmax(ref)
+    assert runner.close() is None
+    hm.close()
+
+
+def test_errors_instead_of_panics(gpu, oracle):
+    cfg, om, hm = build(gpu, oracle, "llama", "f32", max_seq_len=64)
+    hm.seq_reset(1)
+    with pytest.raises(gpu.NvlError) as e:      # rope.go:84-86 panics; we return NVL_ERR_POSITION
+        hm.forward_batch([1], [[1] * 65], [0])
+    assert e.value.code == -2
+    with pytest.raises(gpu.NvlError) as e:      # token id out of range (Go: index out of range panic)
+        hm.forward_batch([1], [[cfg["vocab_size"]]], [0])
+    assert e.value.code == -1
+    with pytest.raises(gpu.NvlError) as e:      # decode for a sequence that was never opened
+        hm.forward_batch([77], [[1]], [3])
+    assert e.value.code == -3
+    with pytest.raises(gpu.NvlError) as e:      # pos_offset must equal the cached length
+        hm.forward_batch([1], [[1]], [5])
+    assert e.value.code == -1
+    hm.close()

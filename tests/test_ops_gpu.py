@@ -1,0 +1,159 @@
+"""Op-level parity: each purego/tensor leaf function on the HIP path (through the C ABI's nvl_op_*
+entry points) against the CPU oracle on the same seeded inputs.
+
+Tolerances (stated, per precision):
+  f32 mode : relative-to-max error <= 2e-5 (fp32 FMA vs the reference's unfused fp32 sums)
+  bf16 mode: relative-to-max error <= 2e-2 (operands rounded to bf16, fp32 accumulate)
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 2e-5
+BF16_TOL = 2e-2
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+@pytest.mark.parametrize("m,k,n", [(1, 64, 128), (7, 128, 100), (130, 256, 257), (256, 2048, 384), (33, 192, 1003)])
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_matmul(gpu, oracle, m, k, n, precision):
+    r = rng(m * 1000 + n)
+    a = r.standard_normal((m, k), dtype=np.float32)
+    b = r.standard_normal((k, n), dtype=np.float32) * 0.05
+    want = oracle.matmul(a, b)
+    got = gpu.ops.mat_mul(a, b, precision=precision)
+    assert got.shape == want.shape
+    assert rel_err(got, want) <= (F32_TOL if precision == "f32" else BF16_TOL)
+
+
+def test_matmul_bf16_exact_on_integers(gpu, oracle):
+    """A=I-style check with ASYMMETRIC B (catches a transposed C write): small integers are exact in bf16."""
+    k, n = 128, 192
+    a = np.zeros((k, k), np.float32)
+    a[np.arange(k), np.arange(k)] = 1.0
+    b = (np.arange(k * n).reshape(k, n) % 251).astype(np.float32)
+    got = gpu.ops.mat_mul(a, b, precision="bf16")
+    assert np.array_equal(got, oracle.matmul(a, b))
+
+
+@pytest.mark.parametrize("rows,hidden", [(1, 64), (5, 768), (9, 2048), (3, 4544)])
+@pytest.mark.parametrize("rms", [True, False])
+def test_layernorm(gpu, oracle, rows, hidden, rms):
+    r = rng(hidden + rows)
+    x = r.standard_normal((rows, hidden), dtype=np.float32) * 3 + 0.5
+    w = 1 + 0.1 * r.standard_normal(hidden, dtype=np.float32)
+    b = None if rms else 0.1 * r.standard_normal(hidden, dtype=np.float32)
+    want = oracle.layernorm(x, w, b, 1e-5)
+    got = gpu.ops.layer_norm(x, w, b, 1e-5)
+    assert rel_err(got, want) <= 1e-5
+
+
+@pytest.mark.parametrize("rows,cols", [(4, 32), (3, 1000), (1, 1)])
+def test_softmax(gpu, oracle, rows, cols):
+    x = rng(cols).standard_normal((rows, cols), dtype=np.float32) * 4
+    assert rel_err(gpu.ops.softmax(x), oracle.softmax(x)) <= 1e-5
+
+
+def test_gelu_silu(gpu, oracle):
+    x = np.linspace(-12, 12, 4097, dtype=np.float32)
+    assert rel_err(gpu.ops.gelu(x), oracle.gelu(x)) <= 1e-5
+    assert rel_err(gpu.ops.silu(x), oracle.silu(x)) <= 1e-5
+
+
+@pytest.mark.parametrize("base", [10000.0, 500000.0])
+@pytest.mark.parametrize("start", [0, 17])
+def test_rope(gpu, oracle, base, start):
+    t = rng(3).standard_normal((3, 9, 64), dtype=np.float32)
+    want = oracle.rope_apply(t, start, base, 64)
+    got = gpu.ops.apply_rope_single_tensor(t, start, base, 64)
+    assert rel_err(got, want) <= 1e-6
+
+
+def test_rope_position_overflow_is_an_error_not_a_panic(gpu, oracle):
+    t = np.zeros((1, 4, 64), np.float32)
+    with pytest.raises(RuntimeError):
+        oracle.rope_apply(t, 62, 10000.0, 64)          # reference panics (rope.go:176)
+    with pytest.raises(gpu.NvlError) as e:
+        gpu.ops.apply_rope_single_tensor(t, 62, 10000.0, 64)
+    assert e.value.code == -2                           # NVL_ERR_POSITION
+
+
+@pytest.mark.parametrize("nH,nKV,S,T", [(4, 2, 5, 5), (4, 2, 1, 70), (2, 2, 33, 100), (3, 1, 7, 64), (71, 1, 2, 130),
+                                        (8, 2, 130, 130)])
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_attention(gpu, oracle, nH, nKV, S, T, precision):
+    r = rng(nH * 100 + T)
+    q = r.standard_normal((nH, S, 64), dtype=np.float32)
+    k = r.standard_normal((nKV, T, 64), dtype=np.float32)
+    v = r.standard_normal((nKV, T, 64), dtype=np.float32)
+    want = oracle.gqa_core(q, k, v)
+    got = gpu.ops.attention(q, k, v, precision=precision)
+    assert rel_err(got, want) <= (5e-5 if precision == "f32" else BF16_TOL)
+
+
+def test_attention_custom_scale_and_hd128(gpu, oracle):
+    r = rng(5)
+    q = r.standard_normal((4, 6, 128), dtype=np.float32)
+    k = r.standard_normal((2, 40, 128), dtype=np.float32)
+    v = r.standard_normal((2, 40, 128), dtype=np.float32)
+    want = oracle.gqa_core(q, k, v, scale=0.015625)
+    for precision, tol in (("f32", 5e-5), ("bf16", BF16_TOL)):
+        assert rel_err(gpu.ops.attention(q, k, v, scale=0.015625, precision=precision), want) <= tol
+
+
+def test_attention_online_softmax_rescale_branch(gpu, oracle):
+    """Force the running max to jump at a later key tile (cdna guide rule 26): spike one key per tile."""
+    r = rng(11)
+    nH, S, T = 2, 4, 200
+    q = r.standard_normal((nH, S, 64), dtype=np.float32)
+    k = r.standard_normal((1, T, 64), dtype=np.float32) * 0.1
+    v = r.standard_normal((1, T, 64), dtype=np.float32)
+    k[0, 70] = q[0, -1] * 3.0      # tile 1
+    k[0, 150] = q[0, -1] * 9.0     # tile 2, much larger
+    want = oracle.gqa_core(q, k, v)
+    assert rel_err(gpu.ops.attention(q, k, v, precision="bf16"), want) <= BF16_TOL
+    assert rel_err(gpu.ops.attention(q, k, v, precision="f32"), want) <= 5e-5
+
+
+@pytest.mark.parametrize("swiglu", [True, False])
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_ffn(gpu, oracle, swiglu, precision):
+    r = rng(7)
+    rows, H, F = 9, 128, 256
+    x = r.standard_normal((rows, H), dtype=np.float32)
+    w1 = r.standard_normal((H, 2 * F if swiglu else F), dtype=np.float32) * 0.1
+    w2 = r.standard_normal((F, H), dtype=np.float32) * 0.1
+    b1 = None if swiglu else r.standard_normal(F, dtype=np.float32) * 0.1
+    b2 = None if swiglu else r.standard_normal(H, dtype=np.float32) * 0.1
+    want = oracle.ffn(x, w1, b1, w2, b2, swiglu)
+    got = gpu.ops.feed_forward(x, w1, b1, w2, b2, swiglu, precision=precision)
+    assert rel_err(got, want) <= (5e-5 if precision == "f32" else BF16_TOL)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_moe(gpu, oracle, precision):
+    r = rng(9)
+    rows, H, E, k, I = 11, 128, 8, 2, 64
+    x = r.standard_normal((rows, H), dtype=np.float32)
+    router = r.standard_normal((H, E), dtype=np.float32) * 0.3
+    w_in = r.standard_normal((E, 2 * I, H), dtype=np.float32) * 0.1
+    w_out = r.standard_normal((E, H, I), dtype=np.float32) * 0.1
+    want = oracle.moe(x, router, w_in, w_out, k)
+    got = gpu.ops.moe_forward(x, router, w_in, w_out, k, precision=precision)
+    # bf16 router logits can reorder near-tied experts; the fixture's margins are far above that
+    assert rel_err(got, want) <= (5e-5 if precision == "f32" else 3e-2)
+
+
+def test_argmax_first_max_tie_rule(gpu, oracle):
+    x = np.zeros((3, 50257), np.float32)
+    x[0, [5, 40000]] = 2.0          # tie -> lowest index (cmd/ask/main.go:396 strict >)
+    x[1, 50256] = 1.0
+    x[2, :] = -1.0                  # all equal -> index 0
+    got = gpu.ops.argmax(x)
+    assert list(got) == [oracle.argmax(x[i]) for i in range(3)] == [5, 50256, 0]
