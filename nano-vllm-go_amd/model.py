@@ -38,8 +38,9 @@ class HipTransformerModel:
     post-load layout (2-D weights [in, out]); arrays may be numpy fp32 or torch tensors (fp32/bf16,
     host or device) — torch device tensors are handed over by pointer with no host copy."""
 
-    def __init__(self, cfg: dict, tensors: dict, *, device: int = 0, precision: str = "bf16",
+    def __init__(self, cfg: dict, tensors: dict | None, *, device: int = 0, precision: str = "bf16",
                  max_seqs: int = 8, max_batch_tokens: int | None = None):
+        """tensors=None defers finalize(): upload() each tensor, then call finalize()."""
         self.cfg = dict(cfg)
         self.lib = L.lib()
         self.h = C.c_void_p()
@@ -47,11 +48,15 @@ class HipTransformerModel:
                               max_batch_tokens=max_batch_tokens or cfg["max_seq_len"], tp_rank=0, tp_size=1)
         self._c = _cfg_struct(cfg)
         L.check(self.lib.nvl_create(C.byref(self._c), C.byref(opts), C.byref(self.h)))
-        for (slot, layer), arr in tensors.items():
-            self.upload(slot, layer, arr)
-        L.check(self.lib.nvl_finalize(self.h), self.h)
         self.V = cfg["vocab_size"]
         self.H = cfg["hidden"]
+        if tensors is not None:
+            for (slot, layer), arr in tensors.items():
+                self.upload(slot, layer, arr)
+            self.finalize()
+
+    def finalize(self):
+        L.check(self.lib.nvl_finalize(self.h), self.h)
 
     # -- weights -----------------------------------------------------------------------------
     def upload(self, slot: str, layer: int, arr, layout: int = L.LAYOUT_IN_OUT):
