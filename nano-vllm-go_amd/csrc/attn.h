@@ -180,6 +180,136 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 decode kernel (one new token per sequence, group <= 16 query heads per kv head).
+// HBM/latency-bound KV read: one workgroup per (sequence, kv head); its NW waves take the 64-key
+// tiles round-robin (split-T inside the workgroup), each with its own online-softmax state, K and
+// V^T fragments loaded straight HBM -> VGPR (nothing is shared between waves, so no LDS staging
+// and no barrier in the loop), and the NW partial results are merged once through LDS
+// (flash-decoding combine, fixed wave order).  Same transposed MFMA dataflow as the prefill kernel.
+// ------------------------------------------------------------------------------------------
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
+    constexpr int KS = HD / 32, DT = HD / 16;
+    __shared__ float red_m[NW][16];
+    __shared__ float red_l[NW][16];
+    __shared__ f32x4 red_o[NW][DT][64];
+    const int seq = blockIdx.y, kvh = blockIdx.x;
+    const int tok = p.seq_tok_start[seq], pos0 = p.seq_pos[seq], slot = p.seq_slot[seq];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fq = lane & 15, fg = lane >> 4;
+    const bool row_ok = fq < p.group;
+    const int head = kvh * p.group + (row_ok ? fq : 0);
+    const bf16_t* qp = (const bf16_t*)p.q + (int64_t)tok * p.q_stride + head * HD;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) qf[ks] = *(const bf16x8*)(qp + ks * 32 + fg * 8);
+    const int n_kt = pos0 / 64 + 1;
+    const bf16_t* kbase = (const bf16_t*)p.kcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
+    const bf16_t* vbase = (const bf16_t*)p.vcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
+
+    f32x4 o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; d++) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int kt = wave; kt < n_kt; kt += NW) {
+        bf16x8 kf[4][KS];
+        bf16x4 vlo[2][DT], vhi[2][DT];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++)
+                kf[t][ks] = *(const bf16x8*)(kbase + (int64_t)(kt * 64 + t * 16 + fq) * HD + ks * 32 + fg * 8);
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int d = 0; d < DT; d++) {
+                const bf16_t* vr = vbase + (int64_t)(d * 16 + fq) * p.Tmax + kt * 64 + u * 32 + fg * 4;
+                vlo[u][d] = *(const bf16x4*)(vr);
+                vhi[u][d] = *(const bf16x4*)(vr + 16);
+            }
+        f32x4 s[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][ks], qf[ks], s[t], 0, 0, 0);
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int key = kt * 64 + t * 16 + fg * 4 + r;
+                float v = s[t][r] * p.scale;
+                v = (key <= pos0) ? v : -INFINITY;
+                s[t][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);     // finite: every tile kt < n_kt holds key kt*64 <= pos0
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float pv = __expf(s[t][r] - m_new);
+                s[t][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < DT; d++) o[d] *= alpha;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            bf16x8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; r++) { pf[r] = (bf16_t)s[2 * u][r]; pf[4 + r] = (bf16_t)s[2 * u + 1][r]; }
+#pragma unroll
+            for (int d = 0; d < DT; d++) {
+                bf16x8 vf;
+#pragma unroll
+                for (int r = 0; r < 4; r++) { vf[r] = vlo[u][d][r]; vf[4 + r] = vhi[u][d][r]; }
+                o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[d], 0, 0, 0);
+            }
+        }
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (fg == 0) { red_m[wave][fq] = m_run; red_l[wave][fq] = l_run; }
+#pragma unroll
+    for (int d = 0; d < DT; d++) red_o[wave][d][lane] = o[d];
+    __syncthreads();
+    if (wave != 0 || !row_ok) return;
+    float mstar = red_m[0][fq];
+#pragma unroll
+    for (int w = 1; w < NW; w++) mstar = fmaxf(mstar, red_m[w][fq]);
+    float L = 0.f;
+    f32x4 O[DT];
+#pragma unroll
+    for (int d = 0; d < DT; d++) O[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const float sc = __expf(red_m[w][fq] - mstar);   // idle waves: exp(-inf) = 0
+        L += red_l[w][fq] * sc;
+#pragma unroll
+        for (int d = 0; d < DT; d++) O[d] += red_o[w][d][lane] * sc;
+    }
+    const float inv = 1.0f / L;
+    bf16_t* op = (bf16_t*)p.out + (int64_t)tok * p.out_stride + head * HD;
+#pragma unroll
+    for (int d = 0; d < DT; d++) {
+        bf16x4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; r++) ov[r] = (bf16_t)(O[d][r] * inv);
+        *(bf16x4*)(op + d * 16 + fg * 4) = ov;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // fp32 parity kernel: block = (query position, head), 256 threads, T <= 8192
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p, int HD) {
@@ -220,10 +350,12 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p, int HD) {
     if ((tid & 63) == 0) red[4 + (tid >> 6)] = lsum;
     __syncthreads();
     const float tot = red[4] + red[5] + red[6] + red[7];
+    for (int j = tid; j < T; j += 256) sc[j] = sc[j] / tot;      // attention.go:463-466
+    __syncthreads();
     float* op = (float*)p.out + (int64_t)tok * p.out_stride + head * HD;
     for (int d = tid; d < HD; d += 256) {
         float acc = 0.f;
-        for (int j = 0; j < T; j++) acc = fmaf(sc[j] / tot, vb[(int64_t)j * HD + d], acc);
+        for (int j = 0; j < T; j++) acc = fmaf(sc[j], vb[(int64_t)j * HD + d], acc);
         op[d] = acc;
     }
 }

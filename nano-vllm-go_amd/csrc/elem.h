@@ -181,35 +181,55 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 // ---------------------------------------------------------------------------------------
 // greedy argmax (cmd/ask/main.go:389-402: first strict maximum) + LogitsScaling divide
-// (generic_model.go:473-477).  One block per row; logits modified in place when scale != 0.
+// (generic_model.go:473-477).  Two passes so a handful of rows still fill the chip:
+//   pass 1: grid (chunks, rows): each block scans ARGMAX_CHUNK logits (scaled in place when
+//           logits_scaling != 0) and writes its (max, first index);
+//   pass 2: one wave per row reduces the chunk winners (ties -> lower index).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void argmax_kernel(float* __restrict__ logits, int ld, int V,
-                                                     float logits_scaling, int32_t* __restrict__ out) {
+constexpr int ARGMAX_CHUNK = 4096;
+
+__device__ __forceinline__ void argmax_merge(float& best, int& bi, float ov, int oi) {
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+}
+
+__global__ __launch_bounds__(256) void argmax_partial_kernel(float* __restrict__ logits, int ld, int V,
+                                                             float logits_scaling, float* __restrict__ pval,
+                                                             int32_t* __restrict__ pidx) {
     __shared__ float sv[4];
     __shared__ int si[4];
-    float* row = logits + (int64_t)blockIdx.x * ld;
+    float* row = logits + (int64_t)blockIdx.y * ld;
+    const int c0 = blockIdx.x * ARGMAX_CHUNK;
+    const int c1 = min(V, c0 + ARGMAX_CHUNK);
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int j = threadIdx.x; j < V; j += 256) {
+#pragma unroll 4
+    for (int j = c0 + threadIdx.x; j < c1; j += 256) {
         float v = row[j];
         if (logits_scaling != 0.f) { v = v / logits_scaling; row[j] = v; }
         if (v > best) { best = v; bi = j; }      // strict >, ascending j => first max per thread
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-    }
+    for (int o = 32; o > 0; o >>= 1) argmax_merge(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; k++)
-            if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
-        if (bi == 0x7fffffff) bi = 0;   // all -inf / NaN: reference returns index 0
-        out[blockIdx.x] = bi;
+        for (int k = 1; k < 4; k++) argmax_merge(best, bi, sv[k], si[k]);
+        pval[blockIdx.y * gridDim.x + blockIdx.x] = best;
+        pidx[blockIdx.y * gridDim.x + blockIdx.x] = bi;
     }
+}
+
+__global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restrict__ pval,
+                                                          const int32_t* __restrict__ pidx, int chunks,
+                                                          int32_t* __restrict__ out) {
+    const int r = blockIdx.x;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = threadIdx.x; c < chunks; c += 64) argmax_merge(best, bi, pval[r * chunks + c], pidx[r * chunks + c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) argmax_merge(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
+    if (threadIdx.x == 0) out[r] = (bi == 0x7fffffff) ? 0 : bi;   // all -inf / NaN: reference returns index 0
 }
 
 // ---------------------------------------------------------------------------------------

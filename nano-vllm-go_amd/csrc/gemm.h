@@ -305,10 +305,110 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 skinny kernel (decode: M <= 64 rows).  The projection is then a weight-streaming problem
+// (HBM-bound: every weight byte is read once, activations are a few hundred KB in L2), so the
+// shape of the kernel is set by memory-level parallelism, not by MFMA:
+//   * one workgroup owns 16*BNT weight rows (output columns) over ALL of K;
+//   * its KSPLIT waves each stream a disjoint K slice of those rows straight HBM -> VGPR with
+//     non-temporal 16-byte loads (no LDS round trip: nothing is shared between waves), several
+//     k-steps in flight per wave, thousands of waves per launch;
+//   * activations (<= 64 x K bf16) are read as MFMA fragments from L2;
+//   * the K slices are reduced through LDS in fixed wave order (deterministic, no atomics) and the
+//     fused epilogue (bias / residual / SwiGLU / GELU) runs once per output element.
+// ------------------------------------------------------------------------------------------
+template <int MT, int BNT, int EPI, typename OutT>
+__global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* red = (f32x4*)smem;                       // [ksplit][MT*BNT][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ksplit = blockDim.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * (16 * BNT);
+    const int kslice = p.K / ksplit;
+    const int kbeg = wave * kslice;
+
+    const bf16_t* wp[BNT];
+    const bf16_t* xp[MT];
+#pragma unroll
+    for (int j = 0; j < BNT; j++) wp[j] = (const bf16_t*)p.W + (int64_t)(n0 + 16 * j + fr) * p.K + kbeg + 8 * fg;
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+        int m = 16 * i + fr;
+        if (m > p.M - 1) m = p.M - 1;
+        xp[i] = (const bf16_t*)p.A + (int64_t)m * p.lda + kbeg + 8 * fg;
+    }
+    f32x4 acc[MT][BNT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < BNT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // k loop: blocks of U k-steps (U*32 of K), two register sets -> the next block's loads are in
+    // flight while the current block's MFMAs issue (the compiler emits counted vmcnt for these).
+    constexpr int U = 4;
+    const int nblk = kslice / (32 * U);
+    bf16x8 wA[U][BNT], xA[U][MT], wB[U][BNT], xB[U][MT];
+    auto load_blk = [&](bf16x8 (&w)[U][BNT], bf16x8 (&x)[U][MT], int b) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int j = 0; j < BNT; j++)
+                w[u][j] = __builtin_nontemporal_load((const bf16x8*)(wp[j] + (b * U + u) * 32));
+#pragma unroll
+            for (int i = 0; i < MT; i++) x[u][i] = *(const bf16x8*)(xp[i] + (b * U + u) * 32);
+        }
+    };
+    auto comp_blk = [&](bf16x8 (&w)[U][BNT], bf16x8 (&x)[U][MT]) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int j = 0; j < BNT; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][j], x[u][i], acc[i][j], 0, 0, 0);
+    };
+    load_blk(wA, xA, 0);
+    int b = 0;
+    for (; b + 2 <= nblk; b += 2) {
+        load_blk(wB, xB, b + 1);
+        comp_blk(wA, xA);
+        if (b + 2 < nblk) load_blk(wA, xA, b + 2);
+        comp_blk(wB, xB);
+    }
+    if (b < nblk) comp_blk(wA, xA);
+    // ---- reduce the K slices in wave order ----
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < BNT; j++) red[(wave * (MT * BNT) + i * BNT + j) * 64 + lane] = acc[i][j];
+    __syncthreads();
+    for (int i = wave; i < MT; i += ksplit) {
+        f32x4 sum[BNT];
+#pragma unroll
+        for (int j = 0; j < BNT; j++) {
+            sum[j] = red[(i * BNT + j) * 64 + lane];
+            for (int w = 1; w < ksplit; w++) sum[j] += red[(w * (MT * BNT) + i * BNT + j) * 64 + lane];
+        }
+        const int m = 16 * i + fr;
+        if (EPI == EPI_SWIGLU) {
+            const int f = (n0 >> 5) * 16 + 4 * fg;      // BNT == 2: rows [gate 16 | up 16]
+            epilogue_swiglu4<OutT>(p, m, f, sum[0], sum[BNT - 1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < BNT; j++) epilogue4<EPI, OutT>(p, m, n0 + 16 * j + 4 * fg, sum[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
 template <int EPI, typename OutT>
+static inline bool launch_gemm_skinny_bf16(hipStream_t st, const GemmArgs& a);
+
+template <int EPI, typename OutT>
 static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
+    if (launch_gemm_skinny_bf16<EPI, OutT>(st, a)) return;
     const int tiles = cdiv(a.M, G_BM) * cdiv(a.N, G_BN);
     static bool attr_set = false;
     if (!attr_set) {
@@ -318,6 +418,25 @@ static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
     }
     hipLaunchKernelGGL((gemm_bf16_kernel<EPI, OutT>), dim3(tiles), dim3(256), G_LDS_BYTES, st, a);
 }
+// skinny dispatch: M <= 64, no gather/segments.  Returns false when the shape is not eligible.
+template <int EPI, typename OutT>
+static inline bool launch_gemm_skinny_bf16(hipStream_t st, const GemmArgs& a) {
+    if (a.M > 64 || a.a_rows || a.seg) return false;
+    constexpr int BNT = (EPI == EPI_SWIGLU) ? 2 : 1;
+    const int MT = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+    const int nblocks = cdiv(a.N, 16 * BNT);
+    int ksplit = 16;
+    while (ksplit > 1 && (a.K % (ksplit * 128) != 0 || ksplit * MT * BNT > 64 || (int64_t)nblocks * ksplit > 16384))
+        ksplit >>= 1;
+    if (a.K % (ksplit * 128) != 0) return false;      // K slices are whole blocks of 4 k-steps
+    const size_t lds = (size_t)ksplit * MT * BNT * 64 * 16;
+    dim3 grid(nblocks), block(ksplit * 64);
+#define NVL_SK(MTv) hipLaunchKernelGGL((gemm_skinny_bf16_kernel<MTv, BNT, EPI, OutT>), grid, block, lds, st, a)
+    if (MT == 1) NVL_SK(1); else if (MT == 2) NVL_SK(2); else NVL_SK(4);
+#undef NVL_SK
+    return true;
+}
+
 template <int EPI, typename OutT>
 static inline void launch_gemm_f32(hipStream_t st, const GemmArgs& a) {
     const int tiles = cdiv(a.M, 64) * cdiv(a.N, 64);

@@ -71,7 +71,7 @@ struct nvl_model {
     void* xn_last = nullptr;     // ActT [rows][H]
     float* logits = nullptr;     // fp32 [logit_rows][Vpad]
     int64_t logit_rows = 0;
-    int32_t* argmax_dev = nullptr;
+    int32_t* argmax_dev = nullptr; float* argmax_pval = nullptr; int32_t* argmax_pidx = nullptr;
     // MoE
     float* router_logits = nullptr;   // [Mmax][128]
     int32_t* expert_ids = nullptr; float* expert_w = nullptr;

@@ -198,7 +198,7 @@ extern "C" void nvl_destroy(nvl_model* m) {
     if (m->lm_head && m->lm_head != m->g[NVL_T_TOK_EMB].p && m->lm_head != m->g[NVL_T_LM_HEAD].p) dfree(m->lm_head);
     dfree(m->rope_cos); dfree(m->rope_sin); dfree(m->kcache); dfree(m->vcache);
     dfree(m->x); dfree(m->xn); dfree(m->qkv); dfree(m->q); dfree(m->attn_out); dfree(m->hbuf); dfree(m->h2);
-    dfree(m->xn_last); dfree(m->logits); dfree(m->argmax_dev); dfree(m->router_logits); dfree(m->expert_ids);
+    dfree(m->xn_last); dfree(m->logits); dfree(m->argmax_dev); dfree(m->argmax_pval); dfree(m->argmax_pidx); dfree(m->router_logits); dfree(m->expert_ids);
     dfree(m->expert_w); dfree(m->seg_start); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo);
     dfree(m->meta_dev); dfree(m->hidden);
     if (m->meta_host) (void)hipHostFree(m->meta_host);
@@ -519,6 +519,8 @@ extern "C" int nvl_finalize(nvl_model* m) {
     m->logit_rows = S;
     m->logits = dmalloc<float>(S * (int64_t)m->Vpad);
     m->argmax_dev = dmalloc<int32_t>(std::max<int64_t>(S, Mmax));
+    m->argmax_pval = dmalloc<float>(std::max<int64_t>(S, Mmax) * cdiv(m->V, ARGMAX_CHUNK));
+    m->argmax_pidx = dmalloc<int32_t>(std::max<int64_t>(S, Mmax) * cdiv(m->V, ARGMAX_CHUNK));
     if (c.use_moe) {
         m->router_logits = dmalloc<float>(Mmax * 128);
         m->expert_ids = dmalloc<int32_t>(Mmax * k);
@@ -609,6 +611,10 @@ void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, do
     if (m->f32) {
         const size_t lds = (size_t)m->Tmax * 4;
         hipLaunchKernelGGL(attn_f32_kernel, dim3(max_len, m->nH, n_seqs), dim3(256), lds, m->stream, a, m->hd);
+    } else if (max_len == 1 && m->group <= 16) {
+        dim3 grid(m->nKV, n_seqs);
+        if (m->hd == 64) hipLaunchKernelGGL((attn_decode_bf16_kernel<64, 8>), grid, dim3(512), 0, m->stream, a);
+        else hipLaunchKernelGGL((attn_decode_bf16_kernel<128, 8>), grid, dim3(512), 0, m->stream, a);
     } else {
         const int qtiles = cdiv((int64_t)max_len * m->group, 64);
         dim3 grid(qtiles, m->nKV, n_seqs);
@@ -633,6 +639,13 @@ void rope_kv(nvl_model* m, int li, const Meta& md, int M) {
                            md.tok_pos, md.tok_slot, m->rope_cos, m->rope_sin, (bf16_t*)m->q, m->nH * m->hd,
                            (bf16_t*)kc, (bf16_t*)vc, m->slot_stride, m->Tmax, m->nH, m->nKV, m->hd);
     NVL_HIP(hipGetLastError());
+}
+
+void launch_argmax(hipStream_t st, float* logits, int ld, int V, int rows, float scaling, float* pval, int32_t* pidx,
+                   int32_t* out) {
+    const int chunks = cdiv(V, ARGMAX_CHUNK);
+    hipLaunchKernelGGL(argmax_partial_kernel, dim3(chunks, rows), dim3(256), 0, st, logits, ld, V, scaling, pval, pidx);
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(rows), dim3(64), 0, st, pval, pidx, chunks, out);
 }
 
 GemmArgs mk(const void* A, int lda, const void* W, void* C, int ldc, const float* bias, float alpha, int M, int N, int K) {
@@ -832,8 +845,8 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
     gemm(m, EPI_STORE, true, mk(m->xn_last, H, m->lm_head, m->logits, m->Vpad, nullptr, 1.f, rows, m->V, H));
     {
         KScope ks(m, KC_OTHER);
-        hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, m->stream, m->logits, m->Vpad, m->V,
-                           c.logits_scaling, m->argmax_dev);
+        launch_argmax(m->stream, m->logits, m->Vpad, m->V, rows, c.logits_scaling, m->argmax_pval, m->argmax_pidx,
+                      m->argmax_dev);
         NVL_HIP(hipGetLastError());
     }
     NVL_HIP(hipEventRecord(m->ev1, m->stream));

@@ -300,7 +300,10 @@ extern "C" int nvl_op_argmax(int device, const float* x, int rows, int cols, int
     OpCtx cx(device, NVL_PRECISION_F32);
     float* dx = cx.up_f32(x, (int64_t)rows * cols);
     int32_t* d = (int32_t*)cx.alloc((int64_t)rows * 4);
-    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, cx.m.stream, dx, cols, cols, 0.f, d);
+    const int chunks = cdiv(cols, ARGMAX_CHUNK);
+    float* pv = (float*)cx.alloc((int64_t)rows * chunks * 4);
+    int32_t* pi = (int32_t*)cx.alloc((int64_t)rows * chunks * 4);
+    launch_argmax(cx.m.stream, dx, cols, cols, rows, 0.f, pv, pi, d);
     NVL_HIP(hipGetLastError());
     NVL_HIP(hipMemcpyAsync(out, d, (size_t)rows * 4, hipMemcpyDeviceToHost, cx.m.stream));
     NVL_HIP(hipStreamSynchronize(cx.m.stream));
