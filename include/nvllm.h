@@ -236,6 +236,14 @@ int nvl_op_moe(int device, int precision, const float* x, const float* router, c
 /* argmax cmd/ask/main.go:389-402 (first strict maximum) */
 int nvl_op_argmax(int device, const float* x, int rows, int cols, int32_t* out);
 
+/* ---- tuning / measurement (no reference counterpart) ----
+ * Times one projection GEMM shape (random bf16 operands resident in HBM) with HIP events on the
+ * library's stream: avg_us per launch over `iters` back-to-back launches.  epi: 0 store-fp32,
+ * 1 residual-add, 2 SwiGLU, 3 GELU.  force_bnt / force_ksplit override the decode kernel's
+ * automatic tile choice (0 = automatic). */
+int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int force_ksplit, int iters,
+                   float* avg_us);
+
 #ifdef __cplusplus
 }
 #endif

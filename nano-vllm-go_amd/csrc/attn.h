@@ -25,7 +25,7 @@ namespace nvl {
 struct AttnArgs {
     const void* q;        // [tokens][q_stride]; head h at column h*HD (bf16 or f32)
     int q_stride;
-    void* out;            // [tokens][out_stride]; head h at column h*HD
+    void* out;            // [tokens][out_stride] (bf16: fragment-major, fp32: row-major); head h at column h*HD
     int out_stride;
     const void* kcache;   // layer base; (slot, kvh) at slot*slot_stride + kvh*Tmax*HD; [Tmax][HD]
     const void* vcache;   // bf16: V^T [HD][Tmax]; f32: [Tmax][HD]
@@ -169,14 +169,9 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
     l_run += __shfl_xor(l_run, 32, 64);
     if (!row_ok) return;
     const float inv = 1.0f / l_run;
-    bf16_t* op = (bf16_t*)p.out + (int64_t)(tok0 + s_idx) * p.out_stride + head * HD;
 #pragma unroll
-    for (int d = 0; d < DT; d++) {
-        bf16x4 ov;
-#pragma unroll
-        for (int r = 0; r < 4; r++) ov[r] = (bf16_t)(o[d][r] * inv);
-        *(bf16x4*)(op + d * 16 + fg * 4) = ov;    // O[q][d = 16d + 4fg + r]
-    }
+    for (int d = 0; d < DT; d++)    // O[q][d = 16d + 4fg + r], written in the next GEMM's operand layout
+        act_store4<bf16_t>((bf16_t*)p.out, tok0 + s_idx, head * HD + d * 16 + fg * 4, p.out_stride, o[d] * inv);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -299,14 +294,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
         for (int d = 0; d < DT; d++) O[d] += red_o[w][d][lane] * sc;
     }
     const float inv = 1.0f / L;
-    bf16_t* op = (bf16_t*)p.out + (int64_t)tok * p.out_stride + head * HD;
 #pragma unroll
-    for (int d = 0; d < DT; d++) {
-        bf16x4 ov;
-#pragma unroll
-        for (int r = 0; r < 4; r++) ov[r] = (bf16_t)(O[d][r] * inv);
-        *(bf16x4*)(op + d * 16 + fg * 4) = ov;
-    }
+    for (int d = 0; d < DT; d++)
+        act_store4<bf16_t>((bf16_t*)p.out, tok, head * HD + d * 16 + fg * 4, p.out_stride, O[d] * inv);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -30,6 +30,32 @@ template <> struct ActIO<bf16_t> {
     __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = (bf16_t)v; }
 };
 
+// ---- operand layouts ------------------------------------------------------------------------
+// bf16 MFMA operands (weights AND the activations handed from kernel to kernel) live in HBM in
+// FRAGMENT-MAJOR order: the [R][K] matrix is cut into 16-row x 32-k operand blocks of
+// v_mfma_f32_16x16x32_bf16, each stored as its 64 lanes' 16-byte fragments back to back (1 KiB),
+// blocks ordered [r/16][k/32].  A wave-instruction then reads/writes one contiguous KiB; an LDS
+// image filled by global_load_lds is lane-linear, so fragment ds_read_b128s are conflict-free.
+// fp32 (parity mode) operands stay row-major.
+__host__ __device__ __forceinline__ int64_t fm_index(int64_t r, int64_t k, int64_t K) {
+    return ((((r >> 4) * (K >> 5) + (k >> 5)) * 64) + (r & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7);
+}
+template <typename T> __device__ __forceinline__ int64_t act_index(int64_t r, int64_t k, int64_t K);
+template <> __device__ __forceinline__ int64_t act_index<float>(int64_t r, int64_t k, int64_t K) { return r * K + k; }
+template <> __device__ __forceinline__ int64_t act_index<bf16_t>(int64_t r, int64_t k, int64_t K) { return fm_index(r, k, K); }
+
+// store 4 consecutive-k activations of row r (k % 4 == 0): one 8-byte (bf16) / 16-byte (fp32) store
+template <typename T> __device__ __forceinline__ void act_store4(T* base, int64_t r, int64_t k, int64_t K, f32x4 v);
+template <> __device__ __forceinline__ void act_store4<float>(float* base, int64_t r, int64_t k, int64_t K, f32x4 v) {
+    *(f32x4*)(base + r * K + k) = v;
+}
+template <> __device__ __forceinline__ void act_store4<bf16_t>(bf16_t* base, int64_t r, int64_t k, int64_t K, f32x4 v) {
+    bf16x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = (bf16_t)v[i];
+    *(bf16x4*)(base + fm_index(r, k, K)) = o;
+}
+
 // ---- wave reductions (64 lanes) ----------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -11,19 +11,20 @@ namespace nvl {
 // ---------------------------------------------------------------------------------------
 // embedWithOffset (generic_model.go:567-592) + EmbeddingMultiplier (:298-302)
 // ---------------------------------------------------------------------------------------
-template <typename WT>
+// FM = true: the tables are in the fragment-major weight layout (fm_index below) — the tied LM head and
+// the embedding table are ONE buffer (generic_loader.go:255-259 ties them; the reference transposes a copy).
+template <typename WT, bool FM>
 __global__ void embed_kernel(const int32_t* __restrict__ tokens, const int32_t* __restrict__ tok_pos,
                              const WT* __restrict__ emb, const WT* __restrict__ pos_emb,
                              int max_seq, float mult, float* __restrict__ x, int H) {
     const int t = blockIdx.x;
     const int tok = tokens[t];
-    const WT* er = emb + (int64_t)tok * H;
     const int pos = tok_pos[t];
-    const WT* pr = (pos_emb && pos < max_seq) ? pos_emb + (int64_t)pos * H : nullptr;
+    const bool use_pos = pos_emb && pos < max_seq;
     float* xr = x + (int64_t)t * H;
     for (int j = threadIdx.x; j < H; j += blockDim.x) {
-        float v = (float)er[j];
-        if (pr) v += (float)pr[j];
+        float v = (float)emb[FM ? fm_index(tok, j, H) : (int64_t)tok * H + j];
+        if (use_pos) v += (float)pos_emb[FM ? fm_index(pos, j, H) : (int64_t)pos * H + j];
         if (mult != 0.f) v *= mult;
         xr[j] = v;
     }
@@ -44,7 +45,6 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x,
     if (r >= rows) return;
     const int src = rows_idx ? rows_idx[r] : r;
     const float* xr = x + (int64_t)src * H;
-    ActT* yr = y + (int64_t)r * H;
     const int H4 = H >> 2;  // H % 4 == 0 for every supported model
     if (b == nullptr) {
         float ss = 0.f;
@@ -57,8 +57,10 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x,
         for (int j = lane; j < H4; j += 64) {
             const f32x4 v = *(const f32x4*)(xr + j * 4);
             const f32x4 ww = *(const f32x4*)(w + j * 4);
+            f32x4 o;
 #pragma unroll
-            for (int k = 0; k < 4; k++) ActIO<ActT>::st(yr + j * 4 + k, (v[k] / rms) * ww[k]);
+            for (int k = 0; k < 4; k++) o[k] = (v[k] / rms) * ww[k];
+            act_store4<ActT>(y, r, j * 4, H, o);
         }
     } else {
         float s = 0.f;
@@ -79,9 +81,10 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x,
             const f32x4 v = *(const f32x4*)(xr + j * 4);
             const f32x4 ww = *(const f32x4*)(w + j * 4);
             const f32x4 bb = *(const f32x4*)(b + j * 4);
+            f32x4 o;
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                ActIO<ActT>::st(yr + j * 4 + k, ((v[k] - mean) / sd) * ww[k] + bb[k]);
+            for (int k = 0; k < 4; k++) o[k] = ((v[k] - mean) / sd) * ww[k] + bb[k];
+            act_store4<ActT>(y, r, j * 4, H, o);
         }
     }
 }
@@ -324,8 +327,9 @@ __device__ __forceinline__ float ld_as_f32(const void* p, int dtype, int64_t i) 
     if (dtype == 1) return (float)((const bf16_t*)p)[i];
     return (float)((const _Float16*)p)[i];
 }
-// dst[n][k] (n < N, k < K) from src in IN_OUT ([K][N]) or OUT_IN ([N][K]) order
-template <typename DT>
+// dst[n][k] (n < N, k < K) from src in IN_OUT ([K][N]) or OUT_IN ([N][K]) order; FM selects the
+// fragment-major destination layout (bf16 MFMA weights), else row-major [N][K].
+template <typename DT, bool FM>
 __global__ void convert_2d_kernel(const void* __restrict__ src, int dtype, int transpose_in,
                                   DT* __restrict__ dst, int64_t N, int64_t K) {
     __shared__ float tile[32][33];
@@ -339,12 +343,12 @@ __global__ void convert_2d_kernel(const void* __restrict__ src, int dtype, int t
         __syncthreads();
         for (int r = ty; r < 32; r += 8) {
             const int64_t n = n0 + r, k = k0 + tx;
-            if (n < N && k < K) dst[n * K + k] = (DT)tile[tx][r];
+            if (n < N && k < K) dst[FM ? fm_index(n, k, K) : n * K + k] = (DT)tile[tx][r];
         }
     } else {
         for (int r = ty; r < 32; r += 8) {
             const int64_t n = n0 + r, k = k0 + tx;
-            if (n < N && k < K) dst[n * K + k] = (DT)ld_as_f32(src, dtype, n * K + k);
+            if (n < N && k < K) dst[FM ? fm_index(n, k, K) : n * K + k] = (DT)ld_as_f32(src, dtype, n * K + k);
         }
     }
 }

@@ -225,10 +225,10 @@ void upload_2d(nvl_model* m, DevTensor* t, const void* data, int dtype, int64_t 
     NVL_HIP(hipMemsetAsync(t->p, 0, (size_t)(Npad * K) * m->wsize, m->stream));
     dim3 grid((unsigned)cdiv(K, 32), (unsigned)cdiv(N, 32));
     if (m->f32)
-        hipLaunchKernelGGL((convert_2d_kernel<float>), grid, dim3(256), 0, m->stream, raw, dtype,
+        hipLaunchKernelGGL((convert_2d_kernel<float, false>), grid, dim3(256), 0, m->stream, raw, dtype,
                            src_is_in_out ? 1 : 0, (float*)t->p, N, K);
-    else
-        hipLaunchKernelGGL((convert_2d_kernel<bf16_t>), grid, dim3(256), 0, m->stream, raw, dtype,
+    else   // bf16 weights (and the embedding tables) live in the fragment-major layout
+        hipLaunchKernelGGL((convert_2d_kernel<bf16_t, true>), grid, dim3(256), 0, m->stream, raw, dtype,
                            src_is_in_out ? 1 : 0, (bf16_t*)t->p, N, K);
     NVL_HIP(hipGetLastError());
     NVL_HIP(hipStreamSynchronize(m->stream));
@@ -362,15 +362,32 @@ extern "C" int nvl_upload_falcon_qkv(nvl_model* m, int layer, const float* qkv) 
 
 namespace {
 
+// dst row r = src row idx[r] (or zeros).  idx must move whole 16-row groups together (it does: the
+// SwiGLU interleave works in blocks of 16), because in the fragment-major bf16 layout the unit that
+// can be relocated is a 16-row n-tile (16*K contiguous elements).
 void gather_rows(nvl_model* m, const void* src, const std::vector<int32_t>& idx, void* dst, int64_t K) {
-    int32_t* didx = dmalloc<int32_t>((int64_t)idx.size());
-    NVL_HIP(hipMemcpyAsync(didx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, m->stream));
+    std::vector<int32_t> use = idx;
+    int64_t unit = K;
+    if (!m->f32) {
+        if (idx.size() % 16) throw std::runtime_error("gather_rows: row count must be a multiple of 16");
+        use.resize(idx.size() / 16);
+        for (size_t t = 0; t < use.size(); t++) {
+            const int32_t r0 = idx[t * 16];
+            for (int c = 1; c < 16; c++)
+                if ((r0 < 0) != (idx[t * 16 + c] < 0) || (r0 >= 0 && (idx[t * 16 + c] != r0 + c || (r0 & 15))))
+                    throw std::runtime_error("gather_rows: permutation does not preserve 16-row tiles");
+            use[t] = r0 < 0 ? -1 : r0 / 16;
+        }
+        unit = 16 * K;
+    }
+    int32_t* didx = dmalloc<int32_t>((int64_t)use.size());
+    NVL_HIP(hipMemcpyAsync(didx, use.data(), use.size() * 4, hipMemcpyHostToDevice, m->stream));
     if (m->f32)
-        hipLaunchKernelGGL((gather_rows_kernel<float>), dim3((unsigned)idx.size()), dim3(256), 0, m->stream,
-                           (const float*)src, didx, (float*)dst, K);
+        hipLaunchKernelGGL((gather_rows_kernel<float>), dim3((unsigned)use.size()), dim3(256), 0, m->stream,
+                           (const float*)src, didx, (float*)dst, unit);
     else
-        hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3((unsigned)idx.size()), dim3(256), 0, m->stream,
-                           (const bf16_t*)src, didx, (bf16_t*)dst, K);
+        hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3((unsigned)use.size()), dim3(256), 0, m->stream,
+                           (const bf16_t*)src, didx, (bf16_t*)dst, unit);
     NVL_HIP(hipGetLastError());
     NVL_HIP(hipStreamSynchronize(m->stream));
     dfree(didx);
@@ -506,16 +523,21 @@ extern "C" int nvl_finalize(nvl_model* m) {
 
     // ---- workspaces
     const int64_t Mmax = m->opts.max_batch_tokens, S = m->opts.max_seqs;
+    const int64_t Mp = round_up(Mmax, 64);   // GEMM operands are whole 16-row tiles; decode reads up to 64 rows
     const int64_t qw = (int64_t)m->nH * hd;
     m->x = dmalloc<float>(Mmax * H);
-    m->xn = dmalloc_bytes(Mmax * H * (int64_t)m->wsize);
+    m->xn = dmalloc_bytes(Mp * H * (int64_t)m->wsize);
     m->qkv = dmalloc<float>(Mmax * m->n_qkv);
     m->q = dmalloc_bytes(Mmax * qw * (int64_t)m->wsize);
-    m->attn_out = dmalloc_bytes(Mmax * qw * (int64_t)m->wsize);
+    m->attn_out = dmalloc_bytes(Mp * qw * (int64_t)m->wsize);
     const int64_t k = c.use_moe ? c.num_experts_per_tok : 1;
-    m->hbuf = dmalloc_bytes(Mmax * k * m->F * (int64_t)m->wsize);
+    m->hbuf = dmalloc_bytes(round_up(Mmax * k, 64) * m->F * (int64_t)m->wsize);
+    NVL_HIP(hipMemset(m->xn, 0, (size_t)(Mp * H) * m->wsize));
+    NVL_HIP(hipMemset(m->attn_out, 0, (size_t)(Mp * qw) * m->wsize));
+    NVL_HIP(hipMemset(m->hbuf, 0, (size_t)(round_up(Mmax * k, 64) * m->F) * m->wsize));
     if (m->f32 && (c.activation_type == NVL_ACT_SWIGLU || c.use_moe)) m->h2 = dmalloc<float>(Mmax * k * 2 * m->F);
-    m->xn_last = dmalloc_bytes(S * H * (int64_t)m->wsize);
+    m->xn_last = dmalloc_bytes(round_up(S, 64) * H * (int64_t)m->wsize);
+    NVL_HIP(hipMemset(m->xn_last, 0, (size_t)(round_up(S, 64) * H) * m->wsize));
     m->logit_rows = S;
     m->logits = dmalloc<float>(S * (int64_t)m->Vpad);
     m->argmax_dev = dmalloc<int32_t>(std::max<int64_t>(S, Mmax));
@@ -651,7 +673,7 @@ void launch_argmax(hipStream_t st, float* logits, int ld, int V, int rows, float
 GemmArgs mk(const void* A, int lda, const void* W, void* C, int ldc, const float* bias, float alpha, int M, int N, int K) {
     GemmArgs a{};
     a.A = A; a.lda = lda; a.a_rows = nullptr; a.W = W; a.C = C; a.ldc = ldc; a.bias = bias; a.alpha = alpha;
-    a.M = M; a.N = N; a.K = K; a.seg = nullptr;
+    a.M = M; a.N = N; a.K = K; a.seg = nullptr; a.c_row0 = 0;
     return a;
 }
 
@@ -786,10 +808,10 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
         const void* pe = (c.position_type == NVL_POS_LEARNED) ? m->g[NVL_T_POS_EMB].p : nullptr;
         const int pe_rows = pe ? (int)std::min<int64_t>(m->g[NVL_T_POS_EMB].rows, c.max_seq_len) : 0;
         if (m->f32)
-            hipLaunchKernelGGL((embed_kernel<float>), dim3(M), dim3(256), 0, m->stream, md.tokens, md.tok_pos,
+            hipLaunchKernelGGL((embed_kernel<float, false>), dim3(M), dim3(256), 0, m->stream, md.tokens, md.tok_pos,
                                (const float*)m->g[NVL_T_TOK_EMB].p, (const float*)pe, pe_rows, c.embedding_multiplier, m->x, H);
         else
-            hipLaunchKernelGGL((embed_kernel<bf16_t>), dim3(M), dim3(256), 0, m->stream, md.tokens, md.tok_pos,
+            hipLaunchKernelGGL((embed_kernel<bf16_t, true>), dim3(M), dim3(256), 0, m->stream, md.tokens, md.tok_pos,
                                (const bf16_t*)m->g[NVL_T_TOK_EMB].p, (const bf16_t*)pe, pe_rows, c.embedding_multiplier, m->x, H);
         NVL_HIP(hipGetLastError());
     }
@@ -838,7 +860,8 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
     if (rows > m->logit_rows) {
         dfree(m->logits); dfree(m->xn_last);
         m->logits = dmalloc<float>((int64_t)rows * m->Vpad);
-        m->xn_last = dmalloc_bytes((int64_t)rows * H * (int64_t)m->wsize);
+        m->xn_last = dmalloc_bytes(round_up(rows, 64) * H * (int64_t)m->wsize);
+        NVL_HIP(hipMemset(m->xn_last, 0, (size_t)(round_up(rows, 64) * H) * m->wsize));
         m->logit_rows = rows;
     }
     norm(m, m->x, all ? nullptr : md.last_rows, m->g[NVL_T_FINAL_NORM_W], m->g[NVL_T_FINAL_NORM_B], m->xn_last, rows);

@@ -27,15 +27,19 @@ struct OpCtx {   // a model-less nvl_model carrying just a stream and the fields
         NVL_HIP(hipMemcpyAsync(d, h, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
         return d;
     }
-    // host fp32 [N][K] (or [K][N] when in_out) -> device activation/weight dtype [Npad][K]
-    void* up_mat(const float* h, int64_t N, int64_t K, bool in_out, int64_t pad_rows_to = 1) {
+    // host fp32 [N][K] (or [K][N] when in_out) -> device [Npad][K] in the kernels' operand layout
+    // (bf16: fragment-major, rows padded to whole tiles; f32: row-major).  row_major=true keeps a bf16
+    // matrix row-major (attention's q and KV slabs are not GEMM operands).
+    void* up_mat(const float* h, int64_t N, int64_t K, bool in_out, int64_t pad_rows_to = 64, bool row_major = false) {
+        const bool weight = !row_major;
         float* raw = up_f32(h, N * K);
         const int64_t Np = round_up(N, pad_rows_to);
         void* d = alloc(Np * K * (int64_t)m.wsize);
         NVL_HIP(hipMemsetAsync(d, 0, (size_t)(Np * K) * m.wsize, m.stream));
         dim3 grid((unsigned)cdiv(K, 32), (unsigned)cdiv(N, 32));
-        if (m.f32) hipLaunchKernelGGL((convert_2d_kernel<float>), grid, dim3(256), 0, m.stream, raw, 0, in_out ? 1 : 0, (float*)d, N, K);
-        else hipLaunchKernelGGL((convert_2d_kernel<bf16_t>), grid, dim3(256), 0, m.stream, raw, 0, in_out ? 1 : 0, (bf16_t*)d, N, K);
+        if (m.f32) hipLaunchKernelGGL((convert_2d_kernel<float, false>), grid, dim3(256), 0, m.stream, raw, 0, in_out ? 1 : 0, (float*)d, N, K);
+        else if (weight) hipLaunchKernelGGL((convert_2d_kernel<bf16_t, true>), grid, dim3(256), 0, m.stream, raw, 0, in_out ? 1 : 0, (bf16_t*)d, N, K);
+        else hipLaunchKernelGGL((convert_2d_kernel<bf16_t, false>), grid, dim3(256), 0, m.stream, raw, 0, in_out ? 1 : 0, (bf16_t*)d, N, K);
         NVL_HIP(hipGetLastError());
         return d;
     }
@@ -184,10 +188,10 @@ extern "C" int nvl_op_attention(int device, int precision, const float* q, const
                 if (m.f32) vc[((size_t)h * Tmax + t) * hd + d] = v[((size_t)h * T + t) * hd + d];
                 else vc[((size_t)h * hd + d) * Tmax + t] = v[((size_t)h * T + t) * hd + d];
             }
-    m.q = cx.up_mat(qt.data(), S, (int64_t)nH * hd, false);
-    m.kcache = cx.up_mat(kc.data(), 1, (int64_t)kc.size(), false);
-    m.vcache = cx.up_mat(vc.data(), 1, (int64_t)vc.size(), false);
-    m.attn_out = cx.alloc((int64_t)S * nH * hd * (int64_t)m.wsize);
+    m.q = cx.up_mat(qt.data(), S, (int64_t)nH * hd, false, 1, true);
+    m.kcache = cx.up_mat(kc.data(), 1, (int64_t)kc.size(), false, 1, true);
+    m.vcache = cx.up_mat(vc.data(), 1, (int64_t)vc.size(), false, 1, true);
+    m.attn_out = cx.alloc(round_up(S, 64) * nH * hd * (int64_t)m.wsize);
     m.nH = nH; m.nKV = nKV; m.group = nH / nKV; m.hd = hd; m.Tmax = Tmax; m.L = 1;
     m.layer_stride = (int64_t)nKV * Tmax * hd; m.slot_stride = m.layer_stride;
     m.attn_scale = scale != 0.f ? scale : 1.0f / std::sqrt((float)hd);
@@ -202,10 +206,15 @@ extern "C" int nvl_op_attention(int device, int precision, const float* q, const
     if (m.f32) {
         cx.down(ot.data(), m.attn_out, (int64_t)ot.size());
     } else {
-        std::vector<uint16_t> ob(ot.size());
+        std::vector<uint16_t> ob((size_t)(round_up(S, 64) * nH * hd));
         NVL_HIP(hipMemcpyAsync(ob.data(), m.attn_out, ob.size() * 2, hipMemcpyDeviceToHost, m.stream));
         NVL_HIP(hipStreamSynchronize(m.stream));
-        for (size_t i = 0; i < ob.size(); i++) { uint32_t u = ((uint32_t)ob[i]) << 16; memcpy(&ot[i], &u, 4); }
+        const int64_t W = (int64_t)nH * hd;     // the kernel wrote the next GEMM's fragment-major operand
+        for (int64_t r = 0; r < S; r++)
+            for (int64_t c = 0; c < W; c++) {
+                uint32_t u = ((uint32_t)ob[(size_t)fm_index(r, c, W)]) << 16;
+                memcpy(&ot[(size_t)(r * W + c)], &u, 4);
+            }
     }
     for (int h = 0; h < nH; h++)
         for (int s = 0; s < S; s++)
@@ -238,7 +247,7 @@ extern "C" int nvl_op_ffn(int device, int precision, const float* x, const float
     if (b1) l.t[NVL_T_B1].p = cx.up_f32(b1, ffn);
     void* w2d = cx.up_mat(w2, hidden, ffn, true, 128);
     float* b2d = b2 ? cx.up_f32(b2, hidden) : nullptr;
-    m.hbuf = cx.alloc((int64_t)rows * ffn * (int64_t)m.wsize);
+    m.hbuf = cx.alloc(round_up(rows, 64) * ffn * (int64_t)m.wsize);
     if (m.f32 && swiglu) m.h2 = (float*)cx.alloc((int64_t)rows * 2 * ffn * 4);
     ffn_up(&m, l, rows);
     float* yd = (float*)cx.alloc((int64_t)rows * hidden * 4);
@@ -262,7 +271,7 @@ extern "C" int nvl_op_moe(int device, int precision, const float* x, const float
     m.xn = cx.up_mat(x, rows, hidden, false);
     LayerW l;
     l.t[NVL_T_ROUTER].p = cx.up_mat(router, n_experts, hidden, true, 128);
-    void* inc = cx.up_mat(w_in, (int64_t)n_experts * 2 * inter, hidden, false);
+    void* inc = cx.up_mat(w_in, (int64_t)n_experts * 2 * inter, hidden, false, 128);
     if (!m.f32) {
         std::vector<int32_t> idx;
         for (int e = 0; e < n_experts; e++) {
@@ -274,14 +283,14 @@ extern "C" int nvl_op_moe(int device, int precision, const float* x, const float
     } else {
         l.moe_in = inc;
     }
-    l.t[NVL_T_MOE_OUT].p = cx.up_mat(w_out, (int64_t)n_experts * hidden, inter, false);
+    l.t[NVL_T_MOE_OUT].p = cx.up_mat(w_out, (int64_t)n_experts * hidden, inter, false, 128);
     const int64_t pairs = (int64_t)rows * top_k;
     m.router_logits = (float*)cx.alloc((int64_t)rows * 128 * 4);
     m.expert_ids = (int32_t*)cx.alloc(pairs * 4); m.expert_w = (float*)cx.alloc(pairs * 4);
     m.seg_start = (int32_t*)cx.alloc((n_experts + 1) * 4);
     m.perm_token = (int32_t*)cx.alloc(pairs * 4); m.slot_of = (int32_t*)cx.alloc(pairs * 4);
     m.moe_eo = (float*)cx.alloc(pairs * hidden * 4);
-    m.hbuf = cx.alloc(pairs * inter * (int64_t)m.wsize);
+    m.hbuf = cx.alloc(round_up(pairs, 64) * inter * (int64_t)m.wsize);
     if (m.f32) m.h2 = (float*)cx.alloc(pairs * 2 * inter * 4);
     m.x = (float*)cx.alloc((int64_t)rows * hidden * 4);
     NVL_HIP(hipMemsetAsync(m.x, 0, (size_t)rows * hidden * 4, m.stream));
@@ -307,6 +316,47 @@ extern "C" int nvl_op_argmax(int device, const float* x, int rows, int cols, int
     NVL_HIP(hipGetLastError());
     NVL_HIP(hipMemcpyAsync(out, d, (size_t)rows * 4, hipMemcpyDeviceToHost, cx.m.stream));
     NVL_HIP(hipStreamSynchronize(cx.m.stream));
+    return NVL_OK;
+    OP_CATCH
+}
+
+
+// Tuning/measurement entry: time one projection GEMM shape on the device with HIP events.
+// epi: 0 STORE(fp32 out) 1 RESID 2 SWIGLU 3 GELU; force_bnt/force_ksplit = 0 -> automatic.
+extern "C" int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int force_ksplit, int iters,
+                              float* avg_us) {
+    if (!avg_us || M <= 0 || N <= 0 || K % 64 || iters <= 0) return op_fail("nvl_bench_gemm: bad arguments");
+    OP_TRY
+    OpCtx cx(device, NVL_PRECISION_BF16);
+    const int64_t Np = round_up(N, 128);
+    std::vector<uint16_t> ha((size_t)round_up(M, 64) * K), hw((size_t)Np * K);
+    uint32_t s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (uint16_t)(0x3c00u + ((s >> 9) & 0x3ffu) - ((s >> 20) & 1u) * 0x8000u * 0); };
+    for (auto& v : ha) { v = rnd(); if (s & 0x80000000u) v |= 0x8000u; }
+    for (auto& v : hw) { v = rnd(); if (s & 0x80000000u) v |= 0x8000u; }
+    void* A = cx.alloc((int64_t)ha.size() * 2);
+    void* W = cx.alloc((int64_t)hw.size() * 2);
+    NVL_HIP(hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
+    NVL_HIP(hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    const int ldc = epi == EPI_SWIGLU ? N / 2 : (int)round_up(N, 4);
+    void* C = cx.alloc(round_up(M, 64) * ldc * 4);
+    NVL_HIP(hipMemset(C, 0, (size_t)round_up(M, 64) * ldc * 4));
+    float* bias = nullptr;
+    if (epi == EPI_GELU) { bias = (float*)cx.alloc((int64_t)N * 4); NVL_HIP(hipMemset(bias, 0, (size_t)N * 4)); }
+    GemmArgs a = mk(A, K, W, C, ldc, bias, 1e-3f, M, N, K);
+    g_force_ntw = force_bnt; g_force_ksplit = force_ksplit;
+    for (int i = 0; i < 3; i++) gemm(&cx.m, epi, epi == EPI_STORE, a);
+    hipEvent_t e0, e1;
+    NVL_HIP(hipEventCreate(&e0)); NVL_HIP(hipEventCreate(&e1));
+    NVL_HIP(hipEventRecord(e0, cx.m.stream));
+    for (int i = 0; i < iters; i++) gemm(&cx.m, epi, epi == EPI_STORE, a);
+    NVL_HIP(hipEventRecord(e1, cx.m.stream));
+    NVL_HIP(hipEventSynchronize(e1));
+    g_force_ntw = 0; g_force_ksplit = 0;
+    float ms = 0.f;
+    NVL_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = ms * 1e3f / (float)iters;
     return NVL_OK;
     OP_CATCH
 }
