@@ -31,8 +31,11 @@ __global__ void embed_kernel(const int32_t* __restrict__ tokens, const int32_t* 
 }
 
 // ---------------------------------------------------------------------------------------
-// LayerNorm / RMSNorm (tensor.go:193-250): one wave per row, 4 rows per 256-thread block.
-// rows_idx (optional) gathers input rows (final norm on the last row of each sequence only).
+// LayerNorm / RMSNorm (tensor.go:193-250).  rows_idx (optional) gathers input rows (final norm on
+// the last row of each sequence only).  Output: the next GEMM's operand (bf16 fragment-major / f32).
+//   norm_kernel      : one wave per row, 4 rows per 256-thread block (prefill: thousands of rows)
+//   norm_row_kernel  : one 256-thread block per row, the row held in registers between the
+//                      reduction and the write (decode: a handful of rows -> latency-bound)
 // ---------------------------------------------------------------------------------------
 template <typename ActT>
 __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x,
@@ -85,6 +88,80 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x,
 #pragma unroll
             for (int k = 0; k < 4; k++) o[k] = ((v[k] - mean) / sd) * ww[k] + bb[k];
             act_store4<ActT>(y, r, j * 4, H, o);
+        }
+    }
+}
+
+constexpr int NORM_ROW_MAXCH = 5;   // float4 chunks per thread: H <= 256*4*5 = 5120
+__device__ __forceinline__ float block256_sum(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float t = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return t;
+}
+template <typename ActT>
+__global__ __launch_bounds__(256) void norm_row_kernel(const float* __restrict__ x,
+                                                       const int32_t* __restrict__ rows_idx,
+                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ b, float eps,
+                                                       ActT* __restrict__ y, int H) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const int src = rows_idx ? rows_idx[r] : r;
+    const float* xr = x + (int64_t)src * H;
+    const int H4 = H >> 2;
+    f32x4 v[NORM_ROW_MAXCH], ww[NORM_ROW_MAXCH], bb[NORM_ROW_MAXCH];
+#pragma unroll
+    for (int c = 0; c < NORM_ROW_MAXCH; c++) {
+        const int j = threadIdx.x + c * 256;
+        v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j < H4) {
+            v[c] = *(const f32x4*)(xr + j * 4);
+            ww[c] = *(const f32x4*)(w + j * 4);
+            if (b) bb[c] = *(const f32x4*)(b + j * 4);
+        }
+    }
+    if (b == nullptr) {
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < NORM_ROW_MAXCH; c++) ss += v[c][0] * v[c][0] + v[c][1] * v[c][1] + v[c][2] * v[c][2] + v[c][3] * v[c][3];
+        const float rms = sqrtf(block256_sum(ss, red) / (float)H + eps);
+#pragma unroll
+        for (int c = 0; c < NORM_ROW_MAXCH; c++) {
+            const int j = threadIdx.x + c * 256;
+            if (j < H4) {
+                f32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; k++) o[k] = (v[c][k] / rms) * ww[c][k];
+                act_store4<ActT>(y, r, j * 4, H, o);
+            }
+        }
+    } else {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NORM_ROW_MAXCH; c++) s += v[c][0] + v[c][1] + v[c][2] + v[c][3];   // zero-filled beyond H
+        const float mean = block256_sum(s, red) / (float)H;
+        float vs = 0.f;
+#pragma unroll
+        for (int c = 0; c < NORM_ROW_MAXCH; c++) {
+            const int j = threadIdx.x + c * 256;
+            if (j < H4) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const float d = v[c][k] - mean; vs += d * d; }
+            }
+        }
+        const float sd = sqrtf(block256_sum(vs, red) / (float)H + eps);
+#pragma unroll
+        for (int c = 0; c < NORM_ROW_MAXCH; c++) {
+            const int j = threadIdx.x + c * 256;
+            if (j < H4) {
+                f32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; k++) o[k] = ((v[c][k] - mean) / sd) * ww[c][k] + bb[c][k];
+                act_store4<ActT>(y, r, j * 4, H, o);
+            }
         }
     }
 }

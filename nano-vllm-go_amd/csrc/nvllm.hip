@@ -611,8 +611,12 @@ template <typename ActT>
 void launch_norm(nvl_model* m, const float* x, const int32_t* rows_idx, const float* w, const float* b,
                  void* y, int rows) {
     KScope ks(m, KC_OTHER);
-    hipLaunchKernelGGL((norm_kernel<ActT>), dim3(cdiv(rows, 4)), dim3(256), 0, m->stream, x, rows_idx, w, b,
-                       m->cfg.norm_eps, (ActT*)y, rows, m->H);
+    if (rows <= 512 && m->H <= 1024 * NORM_ROW_MAXCH)
+        hipLaunchKernelGGL((norm_row_kernel<ActT>), dim3(rows), dim3(256), 0, m->stream, x, rows_idx, w, b,
+                           m->cfg.norm_eps, (ActT*)y, m->H);
+    else
+        hipLaunchKernelGGL((norm_kernel<ActT>), dim3(cdiv(rows, 4)), dim3(256), 0, m->stream, x, rows_idx, w, b,
+                           m->cfg.norm_eps, (ActT*)y, rows, m->H);
 }
 void norm(nvl_model* m, const float* x, const int32_t* rows_idx, const DevTensor& w, const DevTensor& b, void* y, int rows) {
     if (m->f32) launch_norm<float>(m, x, rows_idx, (const float*)w.p, (const float*)b.p, y, rows);

@@ -1,5 +1,5 @@
 import importlib, sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
 from oracle import purego_oracle as O
 p = importlib.import_module('nano-vllm-go_amd')
 def rel(a,b): return float(np.abs(a-b).max()/np.abs(b).max())

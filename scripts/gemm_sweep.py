@@ -1,5 +1,5 @@
 import importlib, sys, ctypes as C
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
 p = importlib.import_module('nano-vllm-go_amd')
 L = p.lib()
 def bench(M,N,K,epi,bnt=0,ks=0,iters=50):
