@@ -204,6 +204,8 @@ int nvl_reset_stats(nvl_model* m);
 const char* nvl_last_error(const nvl_model* m);   /* m may be NULL: last error of nvl_create */
 int nvl_abi_version(void);
 int nvl_device_count(void);                        /* number of visible HIP devices, 0 if none */
+int nvl_sizeof(int which);                         /* 0 nvl_model_config, 1 nvl_runtime_opts, 2 nvl_stats: lets a
+                                                      binding (cgo/ctypes) verify its struct mirrors */
 
 /* ---- op-level entry points (host fp32 in / host fp32 out; used by the parity tests) ----
  * Each runs the SAME device kernel the model path uses, on one op, in `precision`. */

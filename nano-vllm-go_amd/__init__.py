@@ -6,7 +6,7 @@ The directory name is the project's; it is not a Python identifier, so import it
 This package holds only what the path needs: csrc/ (HIP kernels + C ABI) and the host-side mirror of
 the reference's TransformerModel / TensorModelRunner interface.  It never imports oracle/.
 """
-from . import _lib, config, ops, synth  # noqa: F401
+from . import _lib, config, dist, ops, synth  # noqa: F401
 from ._lib import NvlError, declared_symbols, lib  # noqa: F401
 from .model import HipTransformerModel  # noqa: F401
 from .runner import HipModelRunner, Sequence  # noqa: F401

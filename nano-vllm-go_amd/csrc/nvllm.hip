@@ -124,6 +124,15 @@ void gemm(nvl_model* m, int epi, bool out_f32, GemmArgs a) {
 // =================================================================================================
 extern "C" int nvl_abi_version(void) { return NVL_ABI_VERSION; }
 
+extern "C" int nvl_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(nvl_model_config);
+        case 1: return (int)sizeof(nvl_runtime_opts);
+        case 2: return (int)sizeof(nvl_stats);
+        default: return -1;
+    }
+}
+
 extern "C" int nvl_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
