@@ -119,6 +119,7 @@ def lib():
     L.nvl_op_moe.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.nvl_op_argmax.argtypes = [C.c_int, vp, C.c_int, C.c_int, vp]
     L.nvl_bench_gemm.argtypes = [C.c_int] * 8 + [vp]
+    L.nvl_set_tuning.argtypes = [C.c_int, C.c_int]
     _lib = L
     return L
 

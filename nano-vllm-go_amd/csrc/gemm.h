@@ -107,11 +107,17 @@ __device__ __forceinline__ void epilogue_swiglu4(const GemmArgs& p, int m, int f
 }
 
 // ------------------------------------------------------------------------------------------
-// bf16 MFMA kernel (prefill)
+// bf16 MFMA kernel (prefill), one template, three instances chosen per shape by the launcher:
+//   <128,128, 2,2, 2>  4 waves, wave tile  64x64, 2 LDS stages (64 KiB, 2 workgroups/CU): small M, MoE segments
+//   <256,128, 4,2, 3>  8 waves, wave tile  64x64, 3 LDS stages (144 KiB): two K tiles in flight
+//   <256,256, 2,4, 2>  8 waves, wave tile 128x64, 2 LDS stages (128 KiB): least LDS traffic per MFMA
+//                      ((8+4) fragment reads per 32 MFMAs instead of (4+4) per 16) — the large-M default
+// BK = 64 (two MFMA k-steps).  Every operand tile is a run of 1-KiB fragment-major blocks, so one
+// global_load_lds_dwordx4 per block fills LDS lane-linearly and the fragment ds_read_b128s are
+// conflict-free.  Raw s_barrier + counted s_waitcnt vmcnt keep (STAGES-2) later tiles in flight
+// across the barrier (never vmcnt(0) in the steady state of the 3-stage instance).
 // ------------------------------------------------------------------------------------------
-constexpr int G_BM = 128, G_BN = 128, G_BK = 64;
-constexpr int G_TILE_BYTES = G_BM * G_BK * 2;          // 16 KiB per operand tile = 16 blocks of 1 KiB
-constexpr int G_LDS_BYTES = 2 * 2 * G_TILE_BYTES;      // 2 buffers x (A,W) = 64 KiB
+constexpr int G_BK = 64;
 
 // XCD-aware block remap (bijective for any grid size): blocks b and b+8 share an XCD, so give
 // each XCD a contiguous run of tiles -> neighbouring tiles (same A row panel) hit one L2.
@@ -121,15 +127,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + k;
 }
 
-template <int EPI, typename OutT>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
+template <int BM, int BN, int STAGES>
+constexpr int gemm_lds_bytes() { return STAGES * (BM + BN) * G_BK * 2; }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, typename OutT>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && STAGES == 2) ? 2 : 1)
+void gemm_bf16_kernel(GemmArgs p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;   // 16x16 accumulator tiles per wave
+    constexpr int NA = BM / 16 * 2, NB = BN / 16 * 2;               // 1-KiB blocks per stage (A, W)
+    constexpr int PW = (NA + NB) / NW;                               // blocks staged per wave per K tile
+    constexpr int STAGE_BYTES = (BM + BN) * G_BK * 2;
+    static_assert((NA + NB) % NW == 0, "blocks must divide evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_n = (p.N + G_BN - 1) / G_BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (p.N + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = bid % tiles_n, tm = bid / tiles_n;
-    const int m0 = tm * G_BM, n0 = tn * G_BN;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int fr = lane & 15, fg = lane >> 4;
     int row_base = 0;
     if (p.seg) {
         row_base = p.seg[0];
@@ -138,88 +156,213 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     }
     if (m0 >= p.M) return;
 
-    // ---- staging: each operand tile is 16 blocks (8 row-tiles x 2 k-steps) of 1 KiB; wave w moves
-    // blocks 4w..4w+3 of A and of W per K tile, one global_load_lds_dwordx4 each ----
-    const int fr = lane & 15, fg = lane >> 4;
-    const bf16_t* a_src[4];
-    const bf16_t* w_src[4];
+    // ---- staging sources: wave w moves blocks w*PW .. w*PW+PW-1 of the stage's [A blocks | W blocks] list
+    const bf16_t* src[PW];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int blk = wave * 4 + i, rt = blk >> 1, ksb = blk & 1;
-        int am = m0 + rt * 16 + fr;
-        if (am > p.M - 1) am = p.M - 1;                     // clamp: rows >= M are never stored
-        am += row_base;
-        if (p.a_rows) am = p.a_rows[am];
-        a_src[i] = (const bf16_t*)p.A + ((((int64_t)(am >> 4) * (p.K >> 5) + ksb) * 64) + (am & 15) + 16 * fg) * 8;
-        w_src[i] = (const bf16_t*)p.W + (((int64_t)((n0 >> 4) + rt) * (p.K >> 5) + ksb) * 64 + lane) * 8;
+    for (int i = 0; i < PW; i++) {
+        const int blk = wave * PW + i;
+        if (blk < NA) {
+            const int rt = blk >> 1, ksb = blk & 1;
+            int am = m0 + rt * 16 + fr;
+            if (am > p.M - 1) am = p.M - 1;                 // clamp: rows >= M are never stored
+            am += row_base;
+            if (p.a_rows) am = p.a_rows[am];
+            src[i] = (const bf16_t*)p.A + ((((int64_t)(am >> 4) * (p.K >> 5) + ksb) * 64) + (am & 15) + 16 * fg) * 8;
+        } else {
+            const int wb = blk - NA, rt = wb >> 1, ksb = wb & 1;
+            src[i] = (const bf16_t*)p.W + (((int64_t)((n0 >> 4) + rt) * (p.K >> 5) + ksb) * 64 + lane) * 8;
+        }
     }
     auto stage = [&](int buf, int kt) {
-        char* abase = smem + buf * 2 * G_TILE_BYTES + wave * 4096;
-        char* wbase = abase + G_TILE_BYTES;
+        char* base = smem + buf * STAGE_BYTES + wave * (PW * 1024);
         const int64_t koff = (int64_t)kt * 1024;            // 2 k-steps x 512 elements per K tile
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(a_src[i] + koff),
-                (__attribute__((address_space(3))) void*)(abase + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(w_src[i] + koff),
-                (__attribute__((address_space(3))) void*)(wbase + i * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < PW; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
     };
+    auto wait_tiles_in_flight = [&](int tiles) {   // s_waitcnt needs an immediate
+        if (tiles <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (PW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    };
+    static_assert(STAGES == 2 || PW == 6 || PW == 8, "add the immediate for this PW");
 
-    // ---- fragment reads: LDS image [row-tile 0..7][k-step 0..1][lane][16 B] ----
-    const int a_blk_off = wm * 4 * 2048 + lane * 16;   // activation rows (MFMA B operand -> output col m)
-    const int w_blk_off = wn * 4 * 2048 + lane * 16;   // weight rows     (MFMA A operand -> output row n)
+    // ---- fragment reads: stage image [A row-tile][k-step][lane][16 B] then [W row-tile][k-step][lane][16 B]
+    const int a_blk_off = wm * TM * 2048 + lane * 16;                 // activation rows -> MFMA B operand (output col m)
+    const int w_blk_off = NA * 1024 + wn * TN * 2048 + lane * 16;     // weight rows     -> MFMA A operand (output row n)
 
-    f32x4 acc[4][4];
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nt = p.K / G_BK;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; s++)
+        if (s < nt) stage(s, s);
+    wait_tiles_in_flight((nt < STAGES - 1 ? nt : STAGES - 1) - 1);
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
     for (int t = 0; t < nt; t++) {
-        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
-        const char* abuf = smem + (t & 1) * 2 * G_TILE_BYTES;
-        const char* wbuf = abuf + G_TILE_BYTES;
+        if (t + STAGES - 1 < nt) {
+            int nb = cur + STAGES - 1;
+            if (nb >= STAGES) nb -= STAGES;
+            stage(nb, t + STAGES - 1);
+        }
+        const char* sbuf = smem + cur * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            bf16x8 af[4], wf[4];
+            bf16x8 af[TM], wf[TN];
 #pragma unroll
-            for (int i = 0; i < 4; i++) af[i] = *(const bf16x8*)(abuf + a_blk_off + i * 2048 + ks * 1024);
+            for (int j = 0; j < TN; j++) wf[j] = *(const bf16x8*)(sbuf + w_blk_off + j * 2048 + ks * 1024);
 #pragma unroll
-            for (int j = 0; j < 4; j++) wf[j] = *(const bf16x8*)(wbuf + w_blk_off + j * 2048 + ks * 1024);
+            for (int i = 0; i < TM; i++) af[i] = *(const bf16x8*)(sbuf + a_blk_off + i * 2048 + ks * 1024);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++)
+                for (int j = 0; j < TN; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // tile t+1 must have landed; up to STAGES-2 younger tiles may stay in flight
+        int younger = nt - 2 - t;
+        if (younger > STAGES - 2) younger = STAGES - 2;
+        wait_tiles_in_flight(younger);
+        __builtin_amdgcn_s_barrier();
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
     }
 
     // ---- epilogue: lane holds rows n = 4*fg + r of column m = fr of each 16x16 tile ----
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int m = m0 + wm * 64 + i * 16 + fr;
+    for (int i = 0; i < TM; i++) {
+        const int m = m0 + wm * (TM * 16) + i * 16 + fr;
         if (EPI == EPI_SWIGLU) {
 #pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                const int ntile = (n0 + wn * 64 + j * 16) >> 4;   // even: gate block, +1: up block
+            for (int j = 0; j < TN; j += 2) {
+                const int ntile = (n0 + wn * (TN * 16) + j * 16) >> 4;   // even: gate block, +1: up block
                 const int f = (ntile >> 1) * 16 + 4 * fg;
                 epilogue_swiglu4<OutT>(p, m, f, acc[i][j], acc[i][j + 1]);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int n = n0 + wn * 64 + j * 16 + 4 * fg;
-                epilogue4<EPI, OutT>(p, m, n, acc[i][j]);
+            for (int j = 0; j < TN; j++)
+                epilogue4<EPI, OutT>(p, m, n0 + wn * (TN * 16) + j * 16 + 4 * fg, acc[i][j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 MFMA kernel, software-pipelined large-M instance: 256x256 tile, 8 waves (2x4), wave tile
+// 128x64 (8x4 accumulators), K step 32 (one MFMA k-step), FOUR LDS stages of 32 KiB.
+// Three overlapped pipelines per wave:   HBM -> LDS   (global_load_lds, two K steps in flight across the barrier)
+//                                        LDS -> VGPR  (fragment ds_reads of step t+1 issued BEFORE the MFMAs of step t)
+//                                        MFMA         (32 per step on the fragments read during the previous step)
+// so neither the global latency nor the LDS read latency sits in front of the matrix pipe; the one raw
+// s_barrier per step only hands buffers over.  Register sets A/B alternate statically (loop unrolled x2).
+// ------------------------------------------------------------------------------------------
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_pipe_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 256, WAVES_N = 4, TM = 8, TN = 4, STAGES = 4;
+    constexpr int NA = BM / 16, NB = BN / 16;            // 1-KiB blocks per stage (one k-step)
+    constexpr int PW = (NA + NB) / 8;                    // 4 blocks per wave per step
+    constexpr int STAGE_BYTES = (BM + BN) * 32 * 2;      // 32 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % tiles_n, tm = bid / tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int fr = lane & 15, fg = lane >> 4;
+    if (m0 >= p.M) return;
+
+    const bf16_t* src[PW];
+#pragma unroll
+    for (int i = 0; i < PW; i++) {
+        const int blk = wave * PW + i;
+        if (blk < NA) {
+            int am = m0 + blk * 16 + fr;
+            if (am > p.M - 1) am = p.M - 1;
+            src[i] = (const bf16_t*)p.A + (((int64_t)(am >> 4) * (p.K >> 5) * 64) + (am & 15) + 16 * fg) * 8;
+        } else {
+            src[i] = (const bf16_t*)p.W + ((int64_t)((n0 >> 4) + blk - NA) * (p.K >> 5) * 64 + lane) * 8;
+        }
+    }
+    auto stage = [&](int buf, int ks) {
+        char* base = smem + buf * STAGE_BYTES + wave * (PW * 1024);
+#pragma unroll
+        for (int i = 0; i < PW; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)ks * 512),
+                                             (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+    };
+    const int a_off = wm * TM * 1024 + lane * 16;
+    const int w_off = NA * 1024 + wn * TN * 1024 + lane * 16;
+    auto read_frags = [&](bf16x8 (&af)[TM], bf16x8 (&wf)[TN], int buf) {
+        const char* sbuf = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < TN; j++) wf[j] = *(const bf16x8*)(sbuf + w_off + j * 1024);
+#pragma unroll
+        for (int i = 0; i < TM; i++) af[i] = *(const bf16x8*)(sbuf + a_off + i * 1024);
+    };
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mfma_all = [&](bf16x8 (&af)[TM], bf16x8 (&wf)[TN]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    const int nt = p.K >> 5;            // k-steps; K % 64 == 0 -> nt even, nt >= 2
+    stage(0, 0);
+    stage(1, 1);
+    if (nt > 2) stage(2, 2);
+    if (nt > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();       // steps 0 and 1 are in LDS for every wave
+    bf16x8 afA[TM], wfA[TN], afB[TM], wfB[TN];
+    read_frags(afA, wfA, 0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // drain here so the loop body carries no pending LDS reads at its head
+    // one half-iteration: on entry set X holds step t (already read), steps t+1 (landed) and t+2 (maybe in flight)
+    auto half = [&](bf16x8 (&afX)[TM], bf16x8 (&wfX)[TN], bf16x8 (&afY)[TM], bf16x8 (&wfY)[TN], int t) {
+        if (t + 3 < nt) stage((t + 3) & 3, t + 3);
+        if (t + 1 < nt) read_frags(afY, wfY, (t + 1) & 3);
+        mfma_all(afX, wfX);
+        // the fragment reads of step t+1 (issued above, ~500 MFMA cycles ago) are retired here, where the
+        // wait is free; telling the compiler so keeps it from putting lgkmcnt(0) in FRONT of the next MFMAs
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+        // step t+2 must have landed before the next half reads it; step t+3 may stay in flight
+        if (t + 3 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int t = 0; t < nt; t += 2) {
+        half(afA, wfA, afB, wfB, t);
+        half(afB, wfB, afA, wfA, t + 1);
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int m = m0 + wm * (TM * 16) + i * 16 + fr;
+        if (EPI == EPI_SWIGLU) {
+#pragma unroll
+            for (int j = 0; j < TN; j += 2) {
+                const int ntile = (n0 + wn * (TN * 16) + j * 16) >> 4;
+                epilogue_swiglu4<OutT>(p, m, (ntile >> 1) * 16 + 4 * fg, acc[i][j], acc[i][j + 1]);
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                epilogue4<EPI, OutT>(p, m, n0 + wn * (TN * 16) + j * 16 + 4 * fg, acc[i][j]);
         }
     }
 }
@@ -381,6 +524,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 // host launchers
 // ------------------------------------------------------------------------------------------
 static int g_force_ntw = 0, g_force_ksplit = 0;   // tuning overrides (nvl_bench_gemm only)
+static int g_force_tile = 0;                      // 0 automatic, 1: 128x128x2st, 2: 256x128x3st, 3: 256x256x2st
 
 // skinny dispatch: M <= 64, no gather/segments.  Returns false when the shape is not eligible.
 template <int NTW, int EPI, typename OutT>
@@ -407,17 +551,52 @@ static inline bool launch_gemm_skinny_bf16(hipStream_t st, const GemmArgs& a) {
     return launch_gemm_skinny_ntw<1, EPI, OutT>(st, a);
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, typename OutT>
+static inline void launch_gemm_tile(hipStream_t st, const GemmArgs& a) {
+    constexpr int lds = gemm_lds_bytes<BM, BN, STAGES>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, OutT>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, OutT>), dim3(tiles),
+                       dim3(WAVES_M * WAVES_N * 64), lds, st, a);
+}
+
+// how well `tiles` workgroups (one per CU at a time for the big tiles) fill 256 CUs
+static inline double cu_fill(int tiles, int per_cu) {
+    const int slots = 256 * per_cu;
+    return (double)tiles / (double)(cdiv(tiles, slots) * slots);
+}
+
 template <int EPI, typename OutT>
 static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
     if (launch_gemm_skinny_bf16<EPI, OutT>(st, a)) return;
-    const int tiles = cdiv(a.M, G_BM) * cdiv(a.N, G_BN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, OutT>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES);
-        attr_set = true;
+    int tile = g_force_tile;
+    if (tile == 0) {
+        tile = 1;
+        if (!a.seg && a.K >= 128) {
+            const int t3 = cdiv(a.M, 256) * cdiv(a.N, 256), t2 = cdiv(a.M, 256) * cdiv(a.N, 128);
+            if (t3 >= 256 && cu_fill(t3, 1) >= 0.74) tile = 3;
+            else if (t2 >= 256 && cu_fill(t2, 1) >= 0.74) tile = 2;
+        }
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, OutT>), dim3(tiles), dim3(256), G_LDS_BYTES, st, a);
+    if (tile == 4 && !a.seg && !a.a_rows) {
+        static bool attr4 = false;
+        if (!attr4) {
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_pipe_kernel<EPI, OutT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            attr4 = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_pipe_kernel<EPI, OutT>), dim3(cdiv(a.M, 256) * cdiv(a.N, 256)), dim3(512),
+                           128 * 1024, st, a);
+        return;
+    }
+    if (tile == 3) launch_gemm_tile<256, 256, 2, 4, 2, EPI, OutT>(st, a);
+    else if (tile == 2) launch_gemm_tile<256, 128, 4, 2, 3, EPI, OutT>(st, a);
+    else launch_gemm_tile<128, 128, 2, 2, 2, EPI, OutT>(st, a);
 }
 
 template <int EPI, typename OutT>

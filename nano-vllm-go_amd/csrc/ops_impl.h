@@ -345,6 +345,7 @@ extern "C" int nvl_bench_gemm(int device, int M, int N, int K, int epi, int forc
     if (epi == EPI_GELU) { bias = (float*)cx.alloc((int64_t)N * 4); NVL_HIP(hipMemset(bias, 0, (size_t)N * 4)); }
     GemmArgs a = mk(A, K, W, C, ldc, bias, 1e-3f, M, N, K);
     g_force_ntw = force_bnt; g_force_ksplit = force_ksplit;
+    if (M > 64) { g_force_tile = force_bnt; g_force_ntw = 0; }   // prefill shapes: force_bnt selects the tile kernel (1/2)
     for (int i = 0; i < 3; i++) gemm(&cx.m, epi, epi == EPI_STORE, a);
     hipEvent_t e0, e1;
     NVL_HIP(hipEventCreate(&e0)); NVL_HIP(hipEventCreate(&e1));
@@ -352,11 +353,16 @@ extern "C" int nvl_bench_gemm(int device, int M, int N, int K, int epi, int forc
     for (int i = 0; i < iters; i++) gemm(&cx.m, epi, epi == EPI_STORE, a);
     NVL_HIP(hipEventRecord(e1, cx.m.stream));
     NVL_HIP(hipEventSynchronize(e1));
-    g_force_ntw = 0; g_force_ksplit = 0;
+    g_force_ntw = 0; g_force_ksplit = 0; g_force_tile = 0;
     float ms = 0.f;
     NVL_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *avg_us = ms * 1e3f / (float)iters;
     return NVL_OK;
     OP_CATCH
+}
+
+extern "C" int nvl_set_tuning(int key, int value) {
+    if (key == 0) { const int old = g_force_tile; g_force_tile = value; return old; }
+    return -1;
 }

@@ -32,6 +32,29 @@ def test_matmul(gpu, oracle, m, k, n, precision):
     assert rel_err(got, want) <= (F32_TOL if precision == "f32" else BF16_TOL)
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("m,k,n", [(300, 128, 200), (517, 256, 384), (256, 64, 128)])
+def test_matmul_prefill_tile_kernels(gpu, oracle, tile, m, k, n):
+    """All prefill tile instances (128x128x2st, 256x128x3st, 256x256x2st) on ragged M/N edges."""
+    r = rng(m + n)
+    a = r.standard_normal((m, k), dtype=np.float32)
+    b = r.standard_normal((k, n), dtype=np.float32) * 0.05
+    old = gpu.lib().nvl_set_tuning(0, tile)
+    try:
+        got = gpu.ops.mat_mul(a, b, precision="bf16")
+    finally:
+        gpu.lib().nvl_set_tuning(0, old)
+    assert rel_err(got, oracle.matmul(a, b)) <= BF16_TOL
+    ai = np.zeros((m, k), np.float32)
+    ai[np.arange(min(m, k)), np.arange(min(m, k))] = 1.0        # A = I block, asymmetric integer B: exact in bf16
+    bi = (np.arange(k * n).reshape(k, n) % 251).astype(np.float32)
+    old = gpu.lib().nvl_set_tuning(0, tile)
+    try:
+        assert np.array_equal(gpu.ops.mat_mul(ai, bi, precision="bf16"), oracle.matmul(ai, bi))
+    finally:
+        gpu.lib().nvl_set_tuning(0, old)
+
+
 def test_matmul_bf16_exact_on_integers(gpu, oracle):
     """A=I-style check with ASYMMETRIC B (catches a transposed C write): small integers are exact in bf16."""
     k, n = 128, 192
