@@ -15,6 +15,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define NVL_WAVE 64
+// weight matrices are allocated with their row count padded to the largest GEMM N-tile (zero rows), so every
+// tile instance may read a whole tile; outputs beyond N are never stored
+constexpr int64_t W_ROW_PAD = 256;
 
 // ---- bf16 conversions -------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }

@@ -127,6 +127,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + k;
 }
 
+// tile id -> (tm, tn), "grouped" order: ids run down GM row-tiles before moving to the next column
+// tile, so the ~32 workgroups an XCD runs at once (a contiguous id range after xcd_remap) cover a
+// compact GM x (32/GM) patch: every A row-panel chunk pulled into that XCD's L2 is reused by 32/GM
+// column tiles and every W panel chunk by GM row tiles, instead of each tile streaming its own W
+// panel from MALL/HBM (tiles advance through K in near lock-step, so the live window is small).
+__device__ __forceinline__ void tile_coords(int pid, int tiles_m, int tiles_n, int GM, int& tm, int& tn) {
+    const int per_group = GM * tiles_n;
+    const int group = pid / per_group, first = group * GM;
+    const int gsz = (tiles_m - first) < GM ? (tiles_m - first) : GM;
+    const int r = pid - group * per_group;
+    tm = first + r % gsz;
+    tn = r / gsz;
+}
+
 template <int BM, int BN, int STAGES>
 constexpr int gemm_lds_bytes() { return STAGES * (BM + BN) * G_BK * 2; }
 
@@ -143,8 +157,8 @@ void gemm_bf16_kernel(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = bid % tiles_n, tm = bid / tiles_n;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), gridDim.x / tiles_n, tiles_n, NW == 4 ? 8 : 4, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int fr = lane & 15, fg = lane >> 4;
@@ -273,8 +287,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pipe_kernel(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = bid % tiles_n, tm = bid / tiles_n;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), gridDim.x / tiles_n, tiles_n, 4, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int fr = lane & 15, fg = lane >> 4;

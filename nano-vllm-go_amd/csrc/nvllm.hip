@@ -223,12 +223,12 @@ extern "C" void nvl_destroy(nvl_model* m) {
 // =================================================================================================
 namespace {
 
-// canonical device copy: 2-D -> [rows_pad(128)][K] in weight dtype; 1-D -> fp32
+// canonical device copy: 2-D -> [rows_pad(W_ROW_PAD)][K] in weight dtype; 1-D -> fp32
 void upload_2d(nvl_model* m, DevTensor* t, const void* data, int dtype, int64_t N, int64_t K, bool src_is_in_out) {
     const size_t esz = dtype == NVL_DTYPE_F32 ? 4 : 2;
     void* raw = dmalloc_bytes((int64_t)N * K * esz);
     NVL_HIP(hipMemcpyAsync(raw, data, (size_t)N * K * esz, hipMemcpyDefault, m->stream));
-    const int64_t Npad = round_up(N, 128);
+    const int64_t Npad = round_up(N, W_ROW_PAD);
     dfree(t->p);
     t->p = dmalloc_bytes(Npad * K * (int64_t)m->wsize);
     NVL_HIP(hipMemsetAsync(t->p, 0, (size_t)(Npad * K) * m->wsize, m->stream));
@@ -437,7 +437,7 @@ extern "C" int nvl_finalize(nvl_model* m) {
         if (c.block_style == NVL_BLOCK_SEQUENTIAL) need(l.t[NVL_T_FFN_NORM_W].present(), "FFN norm weight");
         // ---- fused QKV [n_qkv_pad][H]: rows Q | K | V (canonical rows are contiguous: plain copies)
         const int64_t nq = (int64_t)m->nH * hd, nkv = (int64_t)m->nKV * hd;
-        const int64_t npad = round_up(m->n_qkv, 128);
+        const int64_t npad = round_up(m->n_qkv, W_ROW_PAD);
         l.w_qkv = dmalloc_bytes(npad * H * (int64_t)m->wsize);
         NVL_HIP(hipMemsetAsync(l.w_qkv, 0, (size_t)(npad * H) * m->wsize, m->stream));
         char* dst = (char*)l.w_qkv;
@@ -483,7 +483,7 @@ extern "C" int nvl_finalize(nvl_model* m) {
             l.n1 = swiglu ? 2 * m->F : m->F;
             if (swiglu && !m->f32) {
                 auto idx = swiglu_interleave(m->F, 0);
-                const int64_t np = round_up(l.n1, 128);
+                const int64_t np = round_up(l.n1, W_ROW_PAD);
                 idx.resize((size_t)np, -1);
                 l.w1 = dmalloc_bytes(np * H * (int64_t)m->wsize);
                 gather_rows(m, l.t[NVL_T_W1].p, idx, l.w1, H);

@@ -68,7 +68,7 @@ extern "C" int nvl_op_matmul(int device, int precision, const float* a, const fl
     OP_TRY
     OpCtx cx(device, precision);
     void* A = cx.up_mat(a, M, K, false);
-    void* W = cx.up_mat(b, N, K, true, 128);
+    void* W = cx.up_mat(b, N, K, true, W_ROW_PAD);
     const int ldc = (int)round_up(N, 4);
     float* C = (float*)cx.alloc((int64_t)M * ldc * 4);
     gemm(&cx.m, EPI_STORE, true, mk(A, K, W, C, ldc, nullptr, 1.f, M, N, K));
@@ -235,17 +235,17 @@ extern "C" int nvl_op_ffn(int device, int precision, const float* x, const float
     m.xn = cx.up_mat(x, rows, hidden, false);
     LayerW l;
     const int n1 = swiglu ? 2 * ffn : ffn;
-    void* w1c = cx.up_mat(w1, n1, hidden, true, 128);   // canonical [n1][H] (gate rows | up rows)
+    void* w1c = cx.up_mat(w1, n1, hidden, true, W_ROW_PAD);   // canonical [n1][H] (gate rows | up rows)
     if (swiglu && !m.f32) {
         auto idx = swiglu_interleave(ffn, 0);
-        idx.resize((size_t)round_up(n1, 128), -1);
+        idx.resize((size_t)round_up(n1, W_ROW_PAD), -1);
         l.w1 = cx.alloc((int64_t)idx.size() * hidden * 2);
         gather_rows(&m, w1c, idx, l.w1, hidden);
     } else {
         l.w1 = w1c;
     }
     if (b1) l.t[NVL_T_B1].p = cx.up_f32(b1, ffn);
-    void* w2d = cx.up_mat(w2, hidden, ffn, true, 128);
+    void* w2d = cx.up_mat(w2, hidden, ffn, true, W_ROW_PAD);
     float* b2d = b2 ? cx.up_f32(b2, hidden) : nullptr;
     m.hbuf = cx.alloc(round_up(rows, 64) * ffn * (int64_t)m.wsize);
     if (m.f32 && swiglu) m.h2 = (float*)cx.alloc((int64_t)rows * 2 * ffn * 4);
@@ -270,8 +270,8 @@ extern "C" int nvl_op_moe(int device, int precision, const float* x, const float
     m.cfg.num_experts = n_experts; m.cfg.num_experts_per_tok = top_k; m.cfg.use_moe = 1; m.cfg.residual_multiplier = 0.f;
     m.xn = cx.up_mat(x, rows, hidden, false);
     LayerW l;
-    l.t[NVL_T_ROUTER].p = cx.up_mat(router, n_experts, hidden, true, 128);
-    void* inc = cx.up_mat(w_in, (int64_t)n_experts * 2 * inter, hidden, false, 128);
+    l.t[NVL_T_ROUTER].p = cx.up_mat(router, n_experts, hidden, true, W_ROW_PAD);
+    void* inc = cx.up_mat(w_in, (int64_t)n_experts * 2 * inter, hidden, false, W_ROW_PAD);
     if (!m.f32) {
         std::vector<int32_t> idx;
         for (int e = 0; e < n_experts; e++) {
@@ -283,7 +283,7 @@ extern "C" int nvl_op_moe(int device, int precision, const float* x, const float
     } else {
         l.moe_in = inc;
     }
-    l.t[NVL_T_MOE_OUT].p = cx.up_mat(w_out, (int64_t)n_experts * hidden, inter, false, 128);
+    l.t[NVL_T_MOE_OUT].p = cx.up_mat(w_out, (int64_t)n_experts * hidden, inter, false, W_ROW_PAD);
     const int64_t pairs = (int64_t)rows * top_k;
     m.router_logits = (float*)cx.alloc((int64_t)rows * 128 * 4);
     m.expert_ids = (int32_t*)cx.alloc(pairs * 4); m.expert_w = (float*)cx.alloc(pairs * 4);
@@ -328,7 +328,7 @@ extern "C" int nvl_bench_gemm(int device, int M, int N, int K, int epi, int forc
     if (!avg_us || M <= 0 || N <= 0 || K % 64 || iters <= 0) return op_fail("nvl_bench_gemm: bad arguments");
     OP_TRY
     OpCtx cx(device, NVL_PRECISION_BF16);
-    const int64_t Np = round_up(N, 128);
+    const int64_t Np = round_up(N, W_ROW_PAD);
     std::vector<uint16_t> ha((size_t)round_up(M, 64) * K), hw((size_t)Np * K);
     uint32_t s = 12345u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (uint16_t)(0x3c00u + ((s >> 9) & 0x3ffu) - ((s >> 20) & 1u) * 0x8000u * 0); };
