@@ -30,6 +30,21 @@ enum GemmEpi {
     EPI_RESID = 1,   // X += alpha * (acc (+bias))      X fp32, in place   (generic_model.go:320-326)
     EPI_SWIGLU = 2,  // C[m, f] = silu(gate) * up        W rows interleaved (transformer.go:50-66)
     EPI_GELU = 3,    // C = gelu_tanh(acc + bias)                           (transformer.go:67-78)
+    EPI_QKV = 4,     // fused QKV projection epilogue (head_dim 64): bias, RoPE on Q and K (rope.go:153-205),
+                     // Q -> q buffer, K -> KV slab [pos][hd], V -> slab V^T [hd][pos]  (replaces the fp32 qkv
+                     // round trip + rope_kv_kernel in prefill; Concatenate tensor.go:283-321)
+};
+
+struct QkvEpi {             // EPI_QKV only
+    const int32_t* tok_pos;
+    const int32_t* tok_slot;
+    const float* cos_t;     // [max_seq][64] or NULL (no RoPE)
+    const float* sin_t;
+    bf16_t* q_out;          // [tokens][nH*64] row-major
+    bf16_t* kcache;         // layer base
+    bf16_t* vcache;
+    int64_t slot_stride;
+    int Tmax, nH, nKV;
 };
 
 struct GemmArgs {
@@ -45,6 +60,7 @@ struct GemmArgs {
     const int32_t* seg;     // optional device {start,end}: rows [start,end) of A (via a_rows if set)
                             // and of C; M is then only the grid bound (MoE expert segments)
     int c_row0;             // row offset added to every output row (set from seg inside the kernel)
+    QkvEpi qkv;             // EPI_QKV
 };
 
 __device__ __forceinline__ float silu_f(float g) { return g / (1.0f + __expf(-g)); }
@@ -104,6 +120,58 @@ __device__ __forceinline__ void epilogue_swiglu4(const GemmArgs& p, int m, int f
 #pragma unroll
     for (int r = 0; r < 4; r++) v[r] = silu_f(g[r]) * u[r];
     act_store4<OutT>((OutT*)p.C, (int64_t)p.c_row0 + m, f, p.ldc, v);
+}
+
+// EPI_QKV: one wave sub-tile of 64 columns = one head (hd 64).  The lane holds, for token m,
+// d = 16j + 4fg + r (j = 0..3): the RoPE partner d+32 is tile j+2 of the SAME lane.
+__device__ __forceinline__ void epilogue_qkv_head(const GemmArgs& p, int m, int head, int fg, f32x4 (&t)[4]) {
+    if (m >= p.M) return;
+    const QkvEpi& q = p.qkv;
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const f32x4 b = *(const f32x4*)(p.bias + head * 64 + 16 * j + 4 * fg);
+            t[j] += b;
+        }
+    }
+    const int pos = q.tok_pos[m];
+    if (head < q.nH + q.nKV && q.cos_t) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const f32x4 c = *(const f32x4*)(q.cos_t + (int64_t)pos * 64 + 16 * j + 4 * fg);
+            const f32x4 s = *(const f32x4*)(q.sin_t + (int64_t)pos * 64 + 16 * j + 4 * fg);
+            const f32x4 x1 = t[j], x2 = t[j + 2];
+            t[j] = x1 * c + (-x2) * s;          // rope.go:196-202 (table halves are duplicates: cos[d+32] == cos[d])
+            t[j + 2] = x2 * c + x1 * s;
+        }
+    }
+    if (head < q.nH) {
+        bf16_t* dst = q.q_out + (int64_t)m * (q.nH * 64) + head * 64 + 4 * fg;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] = (bf16_t)t[j][r];
+            *(bf16x4*)(dst + 16 * j) = o;
+        }
+    } else if (head < q.nH + q.nKV) {
+        const int kvh = head - q.nH;
+        bf16_t* dst = q.kcache + (int64_t)q.tok_slot[m] * q.slot_stride + ((int64_t)kvh * q.Tmax + pos) * 64 + 4 * fg;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] = (bf16_t)t[j][r];
+            *(bf16x4*)(dst + 16 * j) = o;
+        }
+    } else {
+        const int kvh = head - q.nH - q.nKV;
+        bf16_t* dst = q.vcache + (int64_t)q.tok_slot[m] * q.slot_stride + (int64_t)kvh * q.Tmax * 64 + pos;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(int64_t)(16 * j + 4 * fg + r) * q.Tmax] = (bf16_t)t[j][r];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -253,7 +321,11 @@ void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int m = m0 + wm * (TM * 16) + i * 16 + fr;
-        if (EPI == EPI_SWIGLU) {
+        if (EPI == EPI_QKV) {
+            static_assert(TN == 4, "EPI_QKV needs a 64-column wave tile (one head)");
+            const int head = (n0 + wn * 64) >> 6;
+            if (head * 64 < p.N) epilogue_qkv_head(p, m, head, fg, acc[i]);
+        } else if (EPI == EPI_SWIGLU) {
 #pragma unroll
             for (int j = 0; j < TN; j += 2) {
                 const int ntile = (n0 + wn * (TN * 16) + j * 16) >> 4;   // even: gate block, +1: up block
@@ -367,7 +439,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pipe_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int m = m0 + wm * (TM * 16) + i * 16 + fr;
-        if (EPI == EPI_SWIGLU) {
+        if (EPI == EPI_QKV) {
+            const int head = (n0 + wn * 64) >> 6;
+            if (head * 64 < p.N) epilogue_qkv_head(p, m, head, fg, acc[i]);
+        } else if (EPI == EPI_SWIGLU) {
 #pragma unroll
             for (int j = 0; j < TN; j += 2) {
                 const int ntile = (n0 + wn * (TN * 16) + j * 16) >> 4;
@@ -558,6 +633,7 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
 }
 template <int EPI, typename OutT>
 static inline bool launch_gemm_skinny_bf16(hipStream_t st, const GemmArgs& a) {
+    if (EPI == EPI_QKV) return false;               // prefill-only epilogue (a decode workgroup owns 16 columns, not a head)
     if (a.M > 64 || a.a_rows || a.seg) return false;
     if (EPI == EPI_SWIGLU) return launch_gemm_skinny_ntw<2, EPI, OutT>(st, a);
     if (g_force_ntw == 2) return launch_gemm_skinny_ntw<2, EPI, OutT>(st, a);

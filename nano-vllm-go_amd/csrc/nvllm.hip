@@ -111,6 +111,7 @@ void gemm(nvl_model* m, int epi, bool out_f32, GemmArgs a) {
             case EPI_RESID:  launch_gemm_bf16<EPI_RESID, float>(st, a); break;
             case EPI_SWIGLU: launch_gemm_bf16<EPI_SWIGLU, bf16_t>(st, a); break;
             case EPI_GELU:   launch_gemm_bf16<EPI_GELU, bf16_t>(st, a); break;
+            case EPI_QKV:    launch_gemm_bf16<EPI_QKV, bf16_t>(st, a); break;
             default: throw std::runtime_error("gemm: bad epilogue");
         }
     }
@@ -687,6 +688,7 @@ GemmArgs mk(const void* A, int lda, const void* W, void* C, int ldc, const float
     GemmArgs a{};
     a.A = A; a.lda = lda; a.a_rows = nullptr; a.W = W; a.C = C; a.ldc = ldc; a.bias = bias; a.alpha = alpha;
     a.M = M; a.N = N; a.K = K; a.seg = nullptr; a.c_row0 = 0;
+    a.qkv = QkvEpi{};
     return a;
 }
 
@@ -841,8 +843,19 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
     for (int li = 0; li < m->L; li++) {
         const LayerW& l = m->layers[li];
         norm(m, m->x, nullptr, l.t[NVL_T_ATTN_NORM_W], l.t[NVL_T_ATTN_NORM_B], m->xn, M);
-        gemm(m, EPI_STORE, true, mk(m->xn, H, l.w_qkv, m->qkv, m->n_qkv, l.b_qkv, 1.f, M, m->n_qkv, H));
-        rope_kv(m, li, md, M);
+        if (!m->f32 && m->hd == 64 && M > 64) {
+            // prefill: RoPE + Q/K/V placement fused into the projection's epilogue (no fp32 qkv round trip)
+            GemmArgs a = mk(m->xn, H, l.w_qkv, nullptr, 0, l.b_qkv, 1.f, M, m->n_qkv, H);
+            a.qkv.tok_pos = md.tok_pos; a.qkv.tok_slot = md.tok_slot; a.qkv.cos_t = m->rope_cos; a.qkv.sin_t = m->rope_sin;
+            a.qkv.q_out = (bf16_t*)m->q;
+            a.qkv.kcache = (bf16_t*)m->kcache + (int64_t)li * m->layer_stride;
+            a.qkv.vcache = (bf16_t*)m->vcache + (int64_t)li * m->layer_stride;
+            a.qkv.slot_stride = m->slot_stride; a.qkv.Tmax = m->Tmax; a.qkv.nH = m->nH; a.qkv.nKV = m->nKV;
+            gemm(m, EPI_QKV, false, a);
+        } else {
+            gemm(m, EPI_STORE, true, mk(m->xn, H, l.w_qkv, m->qkv, m->n_qkv, l.b_qkv, 1.f, M, m->n_qkv, H));
+            rope_kv(m, li, md, M);
+        }
         attention(m, li, md, n_seqs, max_len, attn_flops);
         const float* bo = (const float*)l.t[NVL_T_BO].p;
         if (parallel) {

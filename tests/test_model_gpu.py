@@ -27,9 +27,10 @@ def build(gpu, oracle, family, precision, peaked=0.0, **over):
 
 @pytest.mark.parametrize("family", FAMILIES)
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
-def test_prefill_logits_hidden_and_kv(gpu, oracle, family, precision):
+@pytest.mark.parametrize("ntok", [37, 131])      # 37: decode-sized kernels (M <= 64); 131: the prefill tile kernels + fused QKV epilogue
+def test_prefill_logits_hidden_and_kv(gpu, oracle, family, precision, ntok):
     cfg, om, hm = build(gpu, oracle, family, precision)
-    toks = np.random.default_rng(1).integers(0, cfg["vocab_size"], 37).tolist()
+    toks = np.random.default_rng(1).integers(0, cfg["vocab_size"], ntok).tolist()
     kv = om.new_cache()
     want, want_h = om.forward_with_cache(toks, kv, 0, want_hidden=True)
     hm.set_debug(True)
