@@ -369,31 +369,44 @@ __global__ void moe_combine_kernel(const float* __restrict__ eo, const int32_t* 
     }
 }
 
-// counting sort of (token, rank) pairs by expert: single block; rows*k up to a few 100k.
-// seg_start[e]..seg_start[e+1] rows of `perm_token` belong to expert e; slot_of[t*k+rank] = sorted row.
-__global__ __launch_bounds__(1024) void moe_sort_kernel(const int32_t* __restrict__ expert_ids, int n_pairs,
-                                                        int E, int top_k, int32_t* __restrict__ seg_start,
-                                                        int32_t* __restrict__ perm_token,
-                                                        int32_t* __restrict__ slot_of) {
-    __shared__ int cnt[64];
-    __shared__ int start[65];
-    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < n_pairs; i += blockDim.x) atomicAdd(&cnt[expert_ids[i]], 1);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int a = 0;
-        for (int e = 0; e < E; e++) { start[e] = a; a += cnt[e]; }
-        start[E] = a;
-        for (int e = 0; e <= E; e++) seg_start[e] = start[e];
+// Counting sort of the (token, rank) pairs by expert, three small launches:
+//   moe_hist_kernel    per-expert pair counts (atomics on E counters; zeroed by the host per call)
+//   moe_scan_kernel    one wave: segment starts, the per-expert placement cursors, and the m-tile table of
+//                      the grouped GEMM launch: tile_map[i] = {expert, row0, nrows, 0}, *n_mtiles
+//   moe_scatter_kernel each pair takes the next row of its expert's segment (atomic cursor).  The row a pair
+//                      lands on can differ from run to run, the VALUES cannot: every pair is computed
+//                      independently and moe_combine_kernel reads them back through slot_of in rank order.
+__global__ void moe_hist_kernel(const int32_t* __restrict__ expert_ids, int n_pairs, int32_t* __restrict__ counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pairs) atomicAdd(&counts[expert_ids[i]], 1);
+}
+__global__ __launch_bounds__(64) void moe_scan_kernel(const int32_t* __restrict__ counts, int E, int BM,
+                                                      int32_t* __restrict__ seg_start, int32_t* __restrict__ cursor,
+                                                      int32_t* __restrict__ tile_map, int32_t* __restrict__ n_mtiles) {
+    if (threadIdx.x != 0) return;
+    int row = 0, nt = 0;
+    for (int e = 0; e < E; e++) {
+        const int c = counts[e];
+        seg_start[e] = row;
+        cursor[e] = row;
+        for (int r = 0; r < c; r += BM) {
+            tile_map[4 * nt] = e; tile_map[4 * nt + 1] = row + r; tile_map[4 * nt + 2] = (c - r < BM) ? (c - r) : BM;
+            tile_map[4 * nt + 3] = 0;
+            nt++;
+        }
+        row += c;
     }
-    __syncthreads();
-    // deterministic placement: expert e's rows ordered by pair index (token-major)
-    for (int e = threadIdx.x; e < E; e += blockDim.x) {
-        int pos = start[e];
-        for (int i = 0; i < n_pairs; i++)
-            if (expert_ids[i] == e) { perm_token[pos] = i / top_k; slot_of[i] = pos; pos++; }
-    }
+    seg_start[E] = row;
+    *n_mtiles = nt;
+}
+__global__ void moe_scatter_kernel(const int32_t* __restrict__ expert_ids, int n_pairs, int top_k,
+                                   int32_t* __restrict__ cursor, int32_t* __restrict__ perm_token,
+                                   int32_t* __restrict__ slot_of) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    const int pos = atomicAdd(&cursor[expert_ids[i]], 1);
+    perm_token[pos] = i / top_k;
+    slot_of[i] = pos;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -60,6 +60,12 @@ struct GemmArgs {
     const int32_t* seg;     // optional device {start,end}: rows [start,end) of A (via a_rows if set)
                             // and of C; M is then only the grid bound (MoE expert segments)
     int c_row0;             // row offset added to every output row (set from seg inside the kernel)
+    // grouped (MoE) launch: m-tile i of the grid is rows [row0, row0+nrows) of expert e, from the device table
+    // tile_map[i] = {e, row0, nrows, 0}; blocks with i >= *n_mtiles exit; expert e's weights start at
+    // W + e * w_expert_stride.  One launch covers every expert (moe.go:99-120 loops experts per token).
+    const int32_t* tile_map;
+    const int32_t* n_mtiles;
+    int64_t w_expert_stride;
     QkvEpi qkv;             // EPI_QKV
 };
 
@@ -226,16 +232,28 @@ void gemm_bf16_kernel(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = (p.N + BN - 1) / BN;
     int tm, tn;
-    tile_coords(xcd_remap(blockIdx.x, gridDim.x), gridDim.x / tiles_n, tiles_n, NW == 4 ? 8 : 4, tm, tn);
+    int row_base = 0;
+    if (p.tile_map) {                      // grouped launch: the m-tile index selects (expert, row segment)
+        tn = blockIdx.x % tiles_n;
+        const int ti = blockIdx.x / tiles_n;
+        if (ti >= *p.n_mtiles) return;
+        const int e = p.tile_map[4 * ti];
+        row_base = p.tile_map[4 * ti + 1];
+        p.M = p.tile_map[4 * ti + 2];
+        p.c_row0 = row_base;
+        p.W = (const bf16_t*)p.W + (int64_t)e * p.w_expert_stride;
+        tm = 0;
+    } else {
+        tile_coords(xcd_remap(blockIdx.x, gridDim.x), gridDim.x / tiles_n, tiles_n, NW == 4 ? 8 : 4, tm, tn);
+        if (p.seg) {
+            row_base = p.seg[0];
+            p.M = p.seg[1] - row_base;
+            p.c_row0 = row_base;
+        }
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int fr = lane & 15, fg = lane >> 4;
-    int row_base = 0;
-    if (p.seg) {
-        row_base = p.seg[0];
-        p.M = p.seg[1] - row_base;
-        p.c_row0 = row_base;
-    }
     if (m0 >= p.M) return;
 
     // ---- staging sources: wave w moves blocks w*PW .. w*PW+PW-1 of the stage's [A blocks | W blocks] list
@@ -479,8 +497,10 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     const int tile = wave / ksplit, kw = wave - tile * ksplit;
     const int fr = lane & 15, fg = lane >> 4;
     const int nt0 = blockIdx.x * NTW;                // first 16-row weight tile of this workgroup
-    const int kslice = p.K / ksplit;
-    const int ks0 = (kw * kslice) >> 5;              // first k-step of this wave
+    // K/32 k-steps dealt over the ksplit waves as evenly as possible (K need not divide: Falcon's 4544 = 142 steps)
+    const int nks = p.K >> 5, q = nks / ksplit, rr = nks - q * ksplit;
+    const int my_steps = q + (kw < rr ? 1 : 0);
+    const int ks0 = kw * q + (kw < rr ? kw : rr);    // first k-step of this wave
 
     const bf16_t* wp = (const bf16_t*)p.W + (((int64_t)(nt0 + tile) * (p.K >> 5) + ks0) * 64 + lane) * 8;
     const bf16_t* xp[MT];
@@ -493,7 +513,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
 
     // k loop: blocks of U k-steps (U*32 of K), two register sets -> the next block's loads are in
     // flight while the current block's MFMAs issue (the compiler emits counted vmcnt for these).
-    const int nblk = kslice / (32 * U);
+    const int nblk = my_steps / U;
     bf16x8 wA[U], xA[U][MT], wB[U], xB[U][MT];
     auto load_blk = [&](bf16x8 (&w)[U], bf16x8 (&x)[U][MT], int b) {
 #pragma unroll
@@ -510,7 +530,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
             for (int i = 0; i < MT; i++)
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u], x[u][i], acc[i], 0, 0, 0);
     };
-    load_blk(wA, xA, 0);
+    if (nblk > 0) load_blk(wA, xA, 0);
     int b = 0;
     for (; b + 2 <= nblk; b += 2) {
         load_blk(wB, xB, b + 1);
@@ -519,6 +539,12 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
         comp_blk(wB, xB);
     }
     if (b < nblk) comp_blk(wA, xA);
+    for (int s = nblk * U; s < my_steps; s++) {      // ragged tail: fewer than U k-steps
+        const bf16x8 w = __builtin_nontemporal_load((const bf16x8*)(wp + (int64_t)s * 512));
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, *(const bf16x8*)(xp[i] + (int64_t)s * 512), acc[i], 0, 0, 0);
+    }
 
     // ---- reduce the K slices in wave order ----
 #pragma unroll
@@ -563,6 +589,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         p.c_row0 = row_base;
     }
     if (m0 >= p.M) return;
+    // (the f32 parity path keeps one launch per expert through `seg`; tile_map is bf16-only)
 
     float acc[4][4];
 #pragma unroll
@@ -622,8 +649,8 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
     const int U = MT <= 2 ? 4 : 2;                       // register budget: (1+MT)*U*2 fragments
     const int nblocks = cdiv(cdiv(a.N, 16), NTW);        // weight rows are padded to 128: all tiles exist
     int ksplit = g_force_ksplit ? g_force_ksplit : 16;
-    while (ksplit > 1 && (a.K % (ksplit * 32 * U) != 0 || ksplit * NTW > 16)) ksplit >>= 1;
-    if (a.K % (ksplit * 32 * U) != 0) return false;      // K slices are whole blocks of U k-steps
+    while (ksplit > 1 && ((a.K >> 5) / ksplit < U || ksplit * NTW > 16)) ksplit >>= 1;   // >= one block of U k-steps per wave
+    if (a.K % 32 != 0) return false;
     const size_t lds = (size_t)NTW * ksplit * MT * 64 * 16;
     dim3 grid(nblocks), block(NTW * ksplit * 64);
 #define NVL_SK(MTv, Uv) hipLaunchKernelGGL((gemm_skinny_bf16_kernel<MTv, NTW, Uv, EPI, OutT>), grid, block, lds, st, a)
@@ -634,7 +661,7 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
 template <int EPI, typename OutT>
 static inline bool launch_gemm_skinny_bf16(hipStream_t st, const GemmArgs& a) {
     if (EPI == EPI_QKV) return false;               // prefill-only epilogue (a decode workgroup owns 16 columns, not a head)
-    if (a.M > 64 || a.a_rows || a.seg) return false;
+    if (a.M > 64 || a.a_rows || a.seg || a.tile_map) return false;
     if (EPI == EPI_SWIGLU) return launch_gemm_skinny_ntw<2, EPI, OutT>(st, a);
     if (g_force_ntw == 2) return launch_gemm_skinny_ntw<2, EPI, OutT>(st, a);
     if (g_force_ntw == 4) return launch_gemm_skinny_ntw<4, EPI, OutT>(st, a);
@@ -662,7 +689,21 @@ static inline double cu_fill(int tiles, int per_cu) {
 }
 
 template <int EPI, typename OutT>
+static inline void launch_gemm_grouped(hipStream_t st, const GemmArgs& a, int max_mtiles) {
+    constexpr int lds = gemm_lds_bytes<128, 128, 2>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<128, 128, 2, 2, 2, EPI, OutT>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, 2, 2, EPI, OutT>), dim3(cdiv(a.N, 128) * max_mtiles), dim3(256),
+                       lds, st, a);
+}
+
+template <int EPI, typename OutT>
 static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
+    if (a.tile_map) { launch_gemm_grouped<EPI, OutT>(st, a, a.M); return; }   // a.M carries the m-tile bound
     if (launch_gemm_skinny_bf16<EPI, OutT>(st, a)) return;
     int tile = g_force_tile;
     if (tile == 0) {

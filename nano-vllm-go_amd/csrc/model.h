@@ -77,6 +77,7 @@ struct nvl_model {
     int32_t* expert_ids = nullptr; float* expert_w = nullptr;
     int32_t *seg_start = nullptr, *perm_token = nullptr, *slot_of = nullptr;
     float* moe_eo = nullptr;          // [Mmax*k][H]
+    int32_t *moe_counts = nullptr, *moe_cursor = nullptr, *moe_tile_map = nullptr, *moe_n_mtiles = nullptr;
     // per-call metadata (one pinned host block mirrored on the device)
     int32_t* meta_host = nullptr; int32_t* meta_dev = nullptr; int64_t meta_ints = 0;
     // debug

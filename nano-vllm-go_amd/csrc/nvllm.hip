@@ -92,8 +92,8 @@ void drain_profile(nvl_model* m) {
 
 // ---- GEMM dispatch ---------------------------------------------------------------------------
 // out_f32: output element type of STORE (fp32 vs activation type)
-void gemm(nvl_model* m, int epi, bool out_f32, GemmArgs a) {
-    KScope ks(m, KC_GEMM, 2.0 * (double)a.M * (double)a.N * (double)a.K);
+void gemm(nvl_model* m, int epi, bool out_f32, GemmArgs a, double flops = -1.0) {
+    KScope ks(m, KC_GEMM, flops >= 0 ? flops : 2.0 * (double)a.M * (double)a.N * (double)a.K);
     hipStream_t st = m->stream;
     if (m->f32) {
         switch (epi) {
@@ -209,7 +209,7 @@ extern "C" void nvl_destroy(nvl_model* m) {
     dfree(m->rope_cos); dfree(m->rope_sin); dfree(m->kcache); dfree(m->vcache);
     dfree(m->x); dfree(m->xn); dfree(m->qkv); dfree(m->q); dfree(m->attn_out); dfree(m->hbuf); dfree(m->h2);
     dfree(m->xn_last); dfree(m->logits); dfree(m->argmax_dev); dfree(m->argmax_pval); dfree(m->argmax_pidx); dfree(m->router_logits); dfree(m->expert_ids);
-    dfree(m->expert_w); dfree(m->seg_start); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo);
+    dfree(m->expert_w); dfree(m->seg_start); dfree(m->moe_counts); dfree(m->moe_cursor); dfree(m->moe_tile_map); dfree(m->moe_n_mtiles); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo);
     dfree(m->meta_dev); dfree(m->hidden);
     if (m->meta_host) (void)hipHostFree(m->meta_host);
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
@@ -525,8 +525,8 @@ extern "C" int nvl_finalize(nvl_model* m) {
     const int64_t kv_elems = m->slot_stride * m->opts.max_seqs;
     m->kcache = dmalloc_bytes(kv_elems * (int64_t)m->wsize);
     m->vcache = dmalloc_bytes(kv_elems * (int64_t)m->wsize);
-    NVL_HIP(hipMemset(m->kcache, 0, (size_t)kv_elems * m->wsize));
-    NVL_HIP(hipMemset(m->vcache, 0, (size_t)kv_elems * m->wsize));
+    NVL_HIP(hipMemsetAsync(m->kcache, 0, (size_t)kv_elems * m->wsize, m->stream));
+    NVL_HIP(hipMemsetAsync(m->vcache, 0, (size_t)kv_elems * m->wsize, m->stream));
     m->slot_len.assign((size_t)m->opts.max_seqs, 0);
     m->free_slots.clear();
     for (int s = m->opts.max_seqs - 1; s >= 0; s--) m->free_slots.push_back(s);
@@ -542,12 +542,12 @@ extern "C" int nvl_finalize(nvl_model* m) {
     m->attn_out = dmalloc_bytes(Mp * qw * (int64_t)m->wsize);
     const int64_t k = c.use_moe ? c.num_experts_per_tok : 1;
     m->hbuf = dmalloc_bytes(round_up(Mmax * k, 64) * m->F * (int64_t)m->wsize);
-    NVL_HIP(hipMemset(m->xn, 0, (size_t)(Mp * H) * m->wsize));
-    NVL_HIP(hipMemset(m->attn_out, 0, (size_t)(Mp * qw) * m->wsize));
-    NVL_HIP(hipMemset(m->hbuf, 0, (size_t)(round_up(Mmax * k, 64) * m->F) * m->wsize));
+    NVL_HIP(hipMemsetAsync(m->xn, 0, (size_t)(Mp * H) * m->wsize, m->stream));
+    NVL_HIP(hipMemsetAsync(m->attn_out, 0, (size_t)(Mp * qw) * m->wsize, m->stream));
+    NVL_HIP(hipMemsetAsync(m->hbuf, 0, (size_t)(round_up(Mmax * k, 64) * m->F) * m->wsize, m->stream));
     if (m->f32 && (c.activation_type == NVL_ACT_SWIGLU || c.use_moe)) m->h2 = dmalloc<float>(Mmax * k * 2 * m->F);
     m->xn_last = dmalloc_bytes(round_up(S, 64) * H * (int64_t)m->wsize);
-    NVL_HIP(hipMemset(m->xn_last, 0, (size_t)(round_up(S, 64) * H) * m->wsize));
+    NVL_HIP(hipMemsetAsync(m->xn_last, 0, (size_t)(round_up(S, 64) * H) * m->wsize, m->stream));
     m->logit_rows = S;
     m->logits = dmalloc<float>(S * (int64_t)m->Vpad);
     m->argmax_dev = dmalloc<int32_t>(std::max<int64_t>(S, Mmax));
@@ -558,6 +558,10 @@ extern "C" int nvl_finalize(nvl_model* m) {
         m->expert_ids = dmalloc<int32_t>(Mmax * k);
         m->expert_w = dmalloc<float>(Mmax * k);
         m->seg_start = dmalloc<int32_t>(c.num_experts + 1);
+        m->moe_counts = dmalloc<int32_t>(c.num_experts);
+        m->moe_cursor = dmalloc<int32_t>(c.num_experts);
+        m->moe_tile_map = dmalloc<int32_t>(4 * (cdiv(Mmax * k, 128) + c.num_experts));
+        m->moe_n_mtiles = dmalloc<int32_t>(4);
         m->perm_token = dmalloc<int32_t>(Mmax * k);
         m->slot_of = dmalloc<int32_t>(Mmax * k);
         m->moe_eo = dmalloc<float>(Mmax * k * H);
@@ -565,6 +569,7 @@ extern "C" int nvl_finalize(nvl_model* m) {
     m->meta_ints = 3 * Mmax + 5 * S + 16;
     NVL_HIP(hipHostMalloc((void**)&m->meta_host, (size_t)m->meta_ints * 4, hipHostMallocDefault));
     m->meta_dev = dmalloc<int32_t>(m->meta_ints);
+    NVL_HIP(hipStreamSynchronize(m->stream));   // every memset/copy above ran on the model's own (non-blocking) stream
     m->finalized = true;
     return NVL_OK;
     NVL_CATCH(m)
@@ -689,6 +694,7 @@ GemmArgs mk(const void* A, int lda, const void* W, void* C, int ldc, const float
     a.A = A; a.lda = lda; a.a_rows = nullptr; a.W = W; a.C = C; a.ldc = ldc; a.bias = bias; a.alpha = alpha;
     a.M = M; a.N = N; a.K = K; a.seg = nullptr; a.c_row0 = 0;
     a.qkv = QkvEpi{};
+    a.tile_map = nullptr; a.n_mtiles = nullptr; a.w_expert_stride = 0;
     return a;
 }
 
@@ -713,42 +719,56 @@ void ffn_up(nvl_model* m, const LayerW& l, int M) {
     }
 }
 
-// MoELayer.Forward (moe.go:43-128): router GEMM -> route -> sort by expert -> per-expert GEMMs on
-// row segments -> combine in rank order into x (with the residual multiplier).
+// MoELayer.Forward (moe.go:43-128): router GEMM -> route (softmax, top-k, renormalise) -> counting sort of
+// the (token, rank) pairs by expert -> ONE grouped gate/up GEMM and ONE grouped down GEMM over all experts
+// (m-tiles mapped to (expert, row segment) by a device table; token rows gathered by per-lane source address)
+// -> combine in rank order into x (with the residual multiplier).  The fp32 parity mode launches per expert.
 void moe(nvl_model* m, const LayerW& l, int M) {
     const nvl_model_config& c = m->cfg;
     const int E = c.num_experts, k = c.num_experts_per_tok, I = m->F, H = m->H;
+    const int pairs = M * k;
     gemm(m, EPI_STORE, true, mk(m->xn, H, l.t[NVL_T_ROUTER].p, m->router_logits, 128, nullptr, 1.f, M, E, H));
     {
         KScope ks(m, KC_OTHER);
+        NVL_HIP(hipMemsetAsync(m->moe_counts, 0, (size_t)E * 4, m->stream));
         hipLaunchKernelGGL(moe_route_kernel, dim3(cdiv(M, 4)), dim3(256), 0, m->stream, m->router_logits, 128, M, E, k,
                            m->expert_ids, m->expert_w);
-        hipLaunchKernelGGL(moe_sort_kernel, dim3(1), dim3(1024), 0, m->stream, m->expert_ids, M * k, E, k, m->seg_start,
-                           m->perm_token, m->slot_of);
+        hipLaunchKernelGGL(moe_hist_kernel, dim3(cdiv(pairs, 256)), dim3(256), 0, m->stream, m->expert_ids, pairs, m->moe_counts);
+        hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(64), 0, m->stream, m->moe_counts, E, 128, m->seg_start, m->moe_cursor,
+                           m->moe_tile_map, m->moe_n_mtiles);
+        hipLaunchKernelGGL(moe_scatter_kernel, dim3(cdiv(pairs, 256)), dim3(256), 0, m->stream, m->expert_ids, pairs, k,
+                           m->moe_cursor, m->perm_token, m->slot_of);
         NVL_HIP(hipGetLastError());
     }
-    const int pairs = M * k;
-    // one launch per expert; the row segment [seg_start[e], seg_start[e+1]) is read on the device, the
-    // grid is bounded by M (a token picks an expert at most once) and surplus blocks exit at once.
-    for (int e = 0; e < E; e++) {
-        const char* win = (const char*)l.moe_in + (size_t)e * 2 * I * H * m->wsize;
-        GemmArgs a = m->f32 ? mk(m->xn, H, win, m->h2, 2 * I, nullptr, 1.f, M, 2 * I, H)
-                            : mk(m->xn, H, win, m->hbuf, I, nullptr, 1.f, M, 2 * I, H);
-        a.a_rows = m->perm_token; a.seg = m->seg_start + e;
-        gemm(m, m->f32 ? EPI_STORE : EPI_SWIGLU, m->f32, a);
-    }
+    const int max_mtiles = cdiv(pairs, 128) + E;      // every expert may end on a partial tile
     if (m->f32) {
-        KScope ks(m, KC_OTHER);
-        const int64_t n = (int64_t)pairs * I;
-        hipLaunchKernelGGL((swiglu_kernel<float>), dim3(cdiv(n, 256)), dim3(256), 0, m->stream, m->h2, (float*)m->hbuf,
-                           (int64_t)pairs, I);
-        NVL_HIP(hipGetLastError());
-    }
-    for (int e = 0; e < E; e++) {
-        const char* wout = (const char*)l.t[NVL_T_MOE_OUT].p + (size_t)e * H * I * m->wsize;
-        GemmArgs a = mk(m->hbuf, I, wout, m->moe_eo, H, nullptr, 1.f, M, H, I);
-        a.seg = m->seg_start + e;
-        gemm(m, EPI_STORE, true, a);
+        for (int e = 0; e < E; e++) {   // grid bounded by M: a token picks an expert at most once; surplus blocks exit
+            const char* win = (const char*)l.moe_in + (size_t)e * 2 * I * H * m->wsize;
+            GemmArgs a = mk(m->xn, H, win, m->h2, 2 * I, nullptr, 1.f, M, 2 * I, H);
+            a.a_rows = m->perm_token; a.seg = m->seg_start + e;
+            gemm(m, EPI_STORE, true, a);
+        }
+        {
+            KScope ks(m, KC_OTHER);
+            const int64_t n = (int64_t)pairs * I;
+            hipLaunchKernelGGL((swiglu_kernel<float>), dim3(cdiv(n, 256)), dim3(256), 0, m->stream, m->h2, (float*)m->hbuf,
+                               (int64_t)pairs, I);
+            NVL_HIP(hipGetLastError());
+        }
+        for (int e = 0; e < E; e++) {
+            const char* wout = (const char*)l.t[NVL_T_MOE_OUT].p + (size_t)e * H * I * m->wsize;
+            GemmArgs a = mk(m->hbuf, I, wout, m->moe_eo, H, nullptr, 1.f, M, H, I);
+            a.seg = m->seg_start + e;
+            gemm(m, EPI_STORE, true, a);
+        }
+    } else {
+        GemmArgs a = mk(m->xn, H, l.moe_in, m->hbuf, I, nullptr, 1.f, max_mtiles, 2 * I, H);
+        a.a_rows = m->perm_token; a.tile_map = m->moe_tile_map; a.n_mtiles = m->moe_n_mtiles;
+        a.w_expert_stride = (int64_t)2 * I * H;
+        gemm(m, EPI_SWIGLU, false, a, 2.0 * pairs * 2 * I * H);
+        GemmArgs d = mk(m->hbuf, I, l.t[NVL_T_MOE_OUT].p, m->moe_eo, H, nullptr, 1.f, max_mtiles, H, I);
+        d.tile_map = m->moe_tile_map; d.n_mtiles = m->moe_n_mtiles; d.w_expert_stride = (int64_t)H * I;
+        gemm(m, EPI_STORE, true, d, 2.0 * pairs * H * I);
     }
     {
         KScope ks(m, KC_OTHER);
@@ -887,7 +907,7 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
         dfree(m->logits); dfree(m->xn_last);
         m->logits = dmalloc<float>((int64_t)rows * m->Vpad);
         m->xn_last = dmalloc_bytes(round_up(rows, 64) * H * (int64_t)m->wsize);
-        NVL_HIP(hipMemset(m->xn_last, 0, (size_t)(round_up(rows, 64) * H) * m->wsize));
+        NVL_HIP(hipMemsetAsync(m->xn_last, 0, (size_t)(round_up(rows, 64) * H) * m->wsize, m->stream));
         m->logit_rows = rows;
     }
     norm(m, m->x, all ? nullptr : md.last_rows, m->g[NVL_T_FINAL_NORM_W], m->g[NVL_T_FINAL_NORM_B], m->xn_last, rows);

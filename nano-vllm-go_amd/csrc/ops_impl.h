@@ -288,6 +288,8 @@ extern "C" int nvl_op_moe(int device, int precision, const float* x, const float
     m.router_logits = (float*)cx.alloc((int64_t)rows * 128 * 4);
     m.expert_ids = (int32_t*)cx.alloc(pairs * 4); m.expert_w = (float*)cx.alloc(pairs * 4);
     m.seg_start = (int32_t*)cx.alloc((n_experts + 1) * 4);
+    m.moe_counts = (int32_t*)cx.alloc(n_experts * 4); m.moe_cursor = (int32_t*)cx.alloc(n_experts * 4);
+    m.moe_tile_map = (int32_t*)cx.alloc(16 * (cdiv(pairs, 128) + n_experts)); m.moe_n_mtiles = (int32_t*)cx.alloc(16);
     m.perm_token = (int32_t*)cx.alloc(pairs * 4); m.slot_of = (int32_t*)cx.alloc(pairs * 4);
     m.moe_eo = (float*)cx.alloc(pairs * hidden * 4);
     m.hbuf = cx.alloc(round_up(pairs, 64) * inter * (int64_t)m.wsize);
@@ -299,6 +301,7 @@ extern "C" int nvl_op_moe(int device, int precision, const float* x, const float
     l.moe_in = nullptr; l.t[NVL_T_ROUTER].p = nullptr; l.t[NVL_T_MOE_OUT].p = nullptr;
     m.xn = m.hbuf = nullptr; m.h2 = nullptr; m.x = nullptr; m.router_logits = nullptr; m.expert_ids = nullptr;
     m.expert_w = nullptr; m.seg_start = m.perm_token = m.slot_of = nullptr; m.moe_eo = nullptr;
+    m.moe_counts = m.moe_cursor = m.moe_tile_map = m.moe_n_mtiles = nullptr;
     return NVL_OK;
     OP_CATCH
 }
@@ -340,9 +343,9 @@ extern "C" int nvl_bench_gemm(int device, int M, int N, int K, int epi, int forc
     NVL_HIP(hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
     const int ldc = epi == EPI_SWIGLU ? N / 2 : (int)round_up(N, 4);
     void* C = cx.alloc(round_up(M, 64) * ldc * 4);
-    NVL_HIP(hipMemset(C, 0, (size_t)round_up(M, 64) * ldc * 4));
+    NVL_HIP(hipMemsetAsync(C, 0, (size_t)round_up(M, 64) * ldc * 4, cx.m.stream));
     float* bias = nullptr;
-    if (epi == EPI_GELU) { bias = (float*)cx.alloc((int64_t)N * 4); NVL_HIP(hipMemset(bias, 0, (size_t)N * 4)); }
+    if (epi == EPI_GELU) { bias = (float*)cx.alloc((int64_t)N * 4); NVL_HIP(hipMemsetAsync(bias, 0, (size_t)N * 4, cx.m.stream)); }
     GemmArgs a = mk(A, K, W, C, ldc, bias, 1e-3f, M, N, K);
     g_force_ntw = force_bnt; g_force_ksplit = force_ksplit;
     if (M > 64) { g_force_tile = force_bnt; g_force_ntw = 0; }   // prefill shapes: force_bnt selects the tile kernel (1/2)
