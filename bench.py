@@ -224,6 +224,17 @@ def main():
     kv_bytes = 2 * cfg["num_layers"] * nKV * cfg["head_dim"] * (S + G / 2) * 2 * B
     dec_gbs = (wbytes + kv_bytes) * G * args.steps / dec_s / 1e9
 
+    # HBM-side traffic of the dominant kernel class comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on
+    # gfx950 + WRITE_SIZE; scripts/pmc_traffic.py), committed under profiles/ — it cannot be sampled from inside
+    # this process.  null when the profile is absent or was taken on another workload.
+    traffic = None
+    try:
+        if args.model == "llama-3.2-1b" and (B, S) == (32, 512) and args.precision == "bf16":
+            traffic = round(json.load(open(ROOT / "profiles" / "r01c_pmc_traffic.json"))
+                            ["prefill_gemm_class_avg_bytes_per_launch"])
+    except Exception:
+        traffic = None
+
     out = {
         "metric": "prefill + decode tokens/sec, Llama-3.2-1B bf16, 1/2/4/8 MI355X",
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -236,7 +247,8 @@ def main():
         "decode_tokens_per_s": round(world * B * G * args.steps / dec_s, 1),
         "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (prefill QKV/O/FFN/LM-head projections)",
                      "achieved": round(gemm_tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(gemm_tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                     "frac": round(gemm_tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                     "traffic_note": "bytes/launch past L2 (incl. Infinity-Cache hits), profiles/r01c_pmc_traffic.json",
                      "launches": int(st["gemm_launches"]),
                      "avg_launch_us": round(1e3 * st["gemm_ms"] / max(1, st["gemm_launches"]), 2)},
         "decode_roofline": {"bound": "hbm", "achieved": round(dec_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
