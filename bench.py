@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-prompt", type=int, default=8)
     ap.add_argument("--cpu-gen", type=int, default=4)
+    ap.add_argument("--tune", default="", help="nvl_set_tuning overrides, e.g. 1=2 (key=value, comma separated)")
     return ap.parse_args()
 
 
@@ -151,6 +152,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        pkg.lib().nvl_set_tuning(int(k), int(v))
     cfg = dict(pkg.synth.FULL_CONFIGS[args.model])
     B, S, G = args.batch, args.prompt, args.gen
     assert S + G <= cfg["max_seq_len"]

@@ -246,7 +246,8 @@ int nvl_op_argmax(int device, const float* x, int rows, int cols, int32_t* out);
 int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int force_ksplit, int iters,
                    float* avg_us);
 /* Process-wide tuning override used by tests and sweeps.  key 0: prefill GEMM kernel (0 automatic,
- * 1 = 128x128 two-stage, 2 = 256x128 three-stage, 3 = 256x256 two-stage).  Returns the previous value. */
+ * 1 = 128x128 two-stage, 2 = 256x128 three-stage, 3 = 256x256 two-stage, 4 = 256x256 pipelined).
+ * key 1: K slices of the decode residual projections (0 automatic, 1 never split, 2, 4).  Returns the previous value. */
 int nvl_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -101,16 +101,25 @@ __device__ __forceinline__ float block256_sum(float v, float* red) {
     __syncthreads();
     return t;
 }
+// Pending residual: the decode GEMMs that precede a norm (O projection, W2) may leave their output as
+// split-K partial slices instead of adding it into x; this kernel then completes the residual add
+// (generic_model.go:320-326,383-389) while it reads the row:  x[row] += alpha * sum_s part[s][row]  (slice order).
+struct PendingResid {
+    const float* part;   // [slices][rows_total][H] or NULL
+    int slices;
+    int rows_total;
+    float alpha;
+};
 template <typename ActT>
-__global__ __launch_bounds__(256) void norm_row_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(256) void norm_row_kernel(float* __restrict__ x,
                                                        const int32_t* __restrict__ rows_idx,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ b, float eps,
-                                                       ActT* __restrict__ y, int H) {
+                                                       ActT* __restrict__ y, int H, PendingResid pr) {
     __shared__ float red[4];
     const int r = blockIdx.x;
     const int src = rows_idx ? rows_idx[r] : r;
-    const float* xr = x + (int64_t)src * H;
+    float* xr = x + (int64_t)src * H;
     const int H4 = H >> 2;
     f32x4 v[NORM_ROW_MAXCH], ww[NORM_ROW_MAXCH], bb[NORM_ROW_MAXCH];
 #pragma unroll
@@ -119,6 +128,13 @@ __global__ __launch_bounds__(256) void norm_row_kernel(const float* __restrict__
         v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (j < H4) {
             v[c] = *(const f32x4*)(xr + j * 4);
+            if (pr.part) {
+                f32x4 s = *(const f32x4*)(pr.part + (int64_t)src * H + j * 4);
+                for (int k = 1; k < pr.slices; k++)
+                    s += *(const f32x4*)(pr.part + ((int64_t)k * pr.rows_total + src) * H + j * 4);
+                v[c] += pr.alpha * s;
+                *(f32x4*)(xr + j * 4) = v[c];
+            }
             ww[c] = *(const f32x4*)(w + j * 4);
             if (b) bb[c] = *(const f32x4*)(b + j * 4);
         }

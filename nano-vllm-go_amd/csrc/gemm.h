@@ -67,6 +67,12 @@ struct GemmArgs {
     const int32_t* n_mtiles;
     int64_t w_expert_stride;
     QkvEpi qkv;             // EPI_QKV
+    // decode kernel, EPI_RESID only: K split over gridDim.y = sk_slices workgroups per column block.  Each
+    // writes its fp32 partial tile to sk_part[slice][m][n] (ld = N) with plain stores; the NEXT kernel in the
+    // stream — the norm that follows every residual add — folds x += alpha * sum(slices) into its read of x.
+    // The kernel boundary is the synchronisation: no fences, no atomics, fixed summation order.
+    float* sk_part;
+    int sk_slices;
 };
 
 __device__ __forceinline__ float silu_f(float g) { return g / (1.0f + __expf(-g)); }
@@ -497,10 +503,12 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     const int tile = wave / ksplit, kw = wave - tile * ksplit;
     const int fr = lane & 15, fg = lane >> 4;
     const int nt0 = blockIdx.x * NTW;                // first 16-row weight tile of this workgroup
-    // K/32 k-steps dealt over the ksplit waves as evenly as possible (K need not divide: Falcon's 4544 = 142 steps)
-    const int nks = p.K >> 5, q = nks / ksplit, rr = nks - q * ksplit;
-    const int my_steps = q + (kw < rr ? 1 : 0);
-    const int ks0 = kw * q + (kw < rr ? kw : rr);    // first k-step of this wave
+    // K/32 k-steps dealt over (gridDim.y slices) x (ksplit waves) as evenly as possible (K need not divide:
+    // Falcon's 4544 = 142 steps)
+    const int nparts = ksplit * gridDim.y, part = blockIdx.y * ksplit + kw;
+    const int nks = p.K >> 5, q = nks / nparts, rr = nks - q * nparts;
+    const int my_steps = q + (part < rr ? 1 : 0);
+    const int ks0 = part * q + (part < rr ? part : rr);   // first k-step of this wave
 
     const bf16_t* wp = (const bf16_t*)p.W + (((int64_t)(nt0 + tile) * (p.K >> 5) + ks0) * 64 + lane) * 8;
     const bf16_t* xp[MT];
@@ -559,6 +567,17 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
         for (int i = wave; i < MT; i += NTW * ksplit) {
             const int f = (nt0 >> 1) * 16 + 4 * fg;    // NTW == 2: tiles [gate 16 | up 16] of features 8*nt0..
             epilogue_swiglu4<OutT>(p, 16 * i + fr, f, ksum(0, i), ksum(NTW - 1, i));
+        }
+    } else if (EPI == EPI_RESID && gridDim.y > 1) {
+        // split-K across workgroups: publish the partial tile (slice 0 carries the bias); the following norm
+        // kernel adds the slices into x in slice order
+        for (int e = wave; e < NTW * MT; e += NTW * ksplit) {
+            const int t = e / MT, i = e - t * MT;
+            const int m = 16 * i + fr, n = (nt0 + t) * 16 + 4 * fg;
+            if (m >= p.M || n >= p.N) continue;
+            f32x4 v = ksum(t, i);
+            if (p.bias && blockIdx.y == 0) v += *(const f32x4*)(p.bias + n);    // N % 4 == 0 for residual widths
+            *(f32x4*)(p.sk_part + ((int64_t)blockIdx.y * p.M + m) * p.N + n) = v;
         }
     } else {
         for (int e = wave; e < NTW * MT; e += NTW * ksplit) {
@@ -648,11 +667,12 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
     const int MT = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
     const int U = MT <= 2 ? 4 : 2;                       // register budget: (1+MT)*U*2 fragments
     const int nblocks = cdiv(cdiv(a.N, 16), NTW);        // weight rows are padded to 128: all tiles exist
+    const int KS = (EPI == EPI_RESID && a.sk_part && a.sk_slices > 1) ? a.sk_slices : 1;
     int ksplit = g_force_ksplit ? g_force_ksplit : 16;
-    while (ksplit > 1 && ((a.K >> 5) / ksplit < U || ksplit * NTW > 16)) ksplit >>= 1;   // >= one block of U k-steps per wave
+    while (ksplit > 1 && ((a.K >> 5) / (ksplit * KS) < U || ksplit * NTW > 16)) ksplit >>= 1;   // >= one block of U k-steps per wave
     if (a.K % 32 != 0) return false;
     const size_t lds = (size_t)NTW * ksplit * MT * 64 * 16;
-    dim3 grid(nblocks), block(NTW * ksplit * 64);
+    dim3 grid(nblocks, KS), block(NTW * ksplit * 64);
 #define NVL_SK(MTv, Uv) hipLaunchKernelGGL((gemm_skinny_bf16_kernel<MTv, NTW, Uv, EPI, OutT>), grid, block, lds, st, a)
     if (MT == 1) NVL_SK(1, 4); else if (MT == 2) NVL_SK(2, 4); else NVL_SK(4, 2);
 #undef NVL_SK

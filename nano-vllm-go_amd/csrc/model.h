@@ -78,6 +78,8 @@ struct nvl_model {
     int32_t *seg_start = nullptr, *perm_token = nullptr, *slot_of = nullptr;
     float* moe_eo = nullptr;          // [Mmax*k][H]
     int32_t *moe_counts = nullptr, *moe_cursor = nullptr, *moe_tile_map = nullptr, *moe_n_mtiles = nullptr;
+    // decode split-K: partial slices of the last residual GEMM, consumed by the next norm launch
+    float* sk_part = nullptr; int sk_max_slices = 4; int pending_slices = 0, pending_rows = 0; float pending_alpha = 1.f;
     // per-call metadata (one pinned host block mirrored on the device)
     int32_t* meta_host = nullptr; int32_t* meta_dev = nullptr; int64_t meta_ints = 0;
     // debug

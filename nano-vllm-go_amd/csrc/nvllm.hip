@@ -210,7 +210,7 @@ extern "C" void nvl_destroy(nvl_model* m) {
     dfree(m->x); dfree(m->xn); dfree(m->qkv); dfree(m->q); dfree(m->attn_out); dfree(m->hbuf); dfree(m->h2);
     dfree(m->xn_last); dfree(m->logits); dfree(m->argmax_dev); dfree(m->argmax_pval); dfree(m->argmax_pidx); dfree(m->router_logits); dfree(m->expert_ids);
     dfree(m->expert_w); dfree(m->seg_start); dfree(m->moe_counts); dfree(m->moe_cursor); dfree(m->moe_tile_map); dfree(m->moe_n_mtiles); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo);
-    dfree(m->meta_dev); dfree(m->hidden);
+    dfree(m->meta_dev); dfree(m->hidden); dfree(m->sk_part);
     if (m->meta_host) (void)hipHostFree(m->meta_host);
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
@@ -566,6 +566,7 @@ extern "C" int nvl_finalize(nvl_model* m) {
         m->slot_of = dmalloc<int32_t>(Mmax * k);
         m->moe_eo = dmalloc<float>(Mmax * k * H);
     }
+    if (!m->f32) m->sk_part = dmalloc<float>((int64_t)m->sk_max_slices * 64 * H);
     m->meta_ints = 3 * Mmax + 5 * S + 16;
     NVL_HIP(hipHostMalloc((void**)&m->meta_host, (size_t)m->meta_ints * 4, hipHostMallocDefault));
     m->meta_dev = dmalloc<int32_t>(m->meta_ints);
@@ -623,17 +624,23 @@ struct Meta {   // device pointers into meta_dev
 };
 
 template <typename ActT>
-void launch_norm(nvl_model* m, const float* x, const int32_t* rows_idx, const float* w, const float* b,
+void launch_norm(nvl_model* m, float* x, const int32_t* rows_idx, const float* w, const float* b,
                  void* y, int rows) {
     KScope ks(m, KC_OTHER);
+    PendingResid pr{nullptr, 0, 0, 0.f};
+    if (m->pending_slices > 0) {            // complete the residual add the previous decode GEMM left as split-K slices
+        pr.part = m->sk_part; pr.slices = m->pending_slices; pr.rows_total = m->pending_rows; pr.alpha = m->pending_alpha;
+        m->pending_slices = 0;
+        if (!(rows <= 512 && m->H <= 1024 * NORM_ROW_MAXCH)) throw std::runtime_error("norm: pending residual needs the row kernel");
+    }
     if (rows <= 512 && m->H <= 1024 * NORM_ROW_MAXCH)
         hipLaunchKernelGGL((norm_row_kernel<ActT>), dim3(rows), dim3(256), 0, m->stream, x, rows_idx, w, b,
-                           m->cfg.norm_eps, (ActT*)y, m->H);
+                           m->cfg.norm_eps, (ActT*)y, m->H, pr);
     else
         hipLaunchKernelGGL((norm_kernel<ActT>), dim3(cdiv(rows, 4)), dim3(256), 0, m->stream, x, rows_idx, w, b,
                            m->cfg.norm_eps, (ActT*)y, rows, m->H);
 }
-void norm(nvl_model* m, const float* x, const int32_t* rows_idx, const DevTensor& w, const DevTensor& b, void* y, int rows) {
+void norm(nvl_model* m, float* x, const int32_t* rows_idx, const DevTensor& w, const DevTensor& b, void* y, int rows) {
     if (m->f32) launch_norm<float>(m, x, rows_idx, (const float*)w.p, (const float*)b.p, y, rows);
     else launch_norm<bf16_t>(m, x, rows_idx, (const float*)w.p, (const float*)b.p, y, rows);
     NVL_HIP(hipGetLastError());
@@ -695,7 +702,30 @@ GemmArgs mk(const void* A, int lda, const void* W, void* C, int ldc, const float
     a.M = M; a.N = N; a.K = K; a.seg = nullptr; a.c_row0 = 0;
     a.qkv = QkvEpi{};
     a.tile_map = nullptr; a.n_mtiles = nullptr; a.w_expert_stride = 0;
+    a.sk_part = nullptr; a.sk_slices = 1;
     return a;
+}
+
+// Residual projection (O projection / W2): x += alpha * (A·W^T + bias)   (generic_model.go:320-326,383-389).
+// Prefill and the fp32 mode fuse the add into the GEMM epilogue.  Decode-sized batches split K over
+// `slices` workgroups per column block so that all 256 CUs stream weights (a 2048-column projection has
+// only 128 column blocks), and leave the add to the norm kernel that always follows (PendingResid).
+static int g_sk_slices = 0;    // tuning override (nvl_set_tuning key 1): 0 automatic, 1 = never split
+void resid_gemm(nvl_model* m, const void* A, int lda, const void* W, const float* bias, float alpha, int M, int N, int K) {
+    GemmArgs a = mk(A, lda, W, m->x, N, bias, alpha, M, N, K);
+    int slices = 1;
+    if (!m->f32 && M <= 64 && !m->keep_hidden && m->sk_part && m->pending_slices == 0 && N % 16 == 0) {
+        const int nblocks = N / 16;
+        if (g_sk_slices > 0) slices = g_sk_slices;
+        else while (slices < m->sk_max_slices && nblocks * slices < 512 && (K >> 5) / (slices * 2) >= 8) slices *= 2;
+    }
+    if (slices > 1) {
+        a.sk_part = m->sk_part; a.sk_slices = slices;
+        gemm(m, EPI_RESID, true, a);
+        m->pending_slices = slices; m->pending_rows = M; m->pending_alpha = alpha;
+    } else {
+        gemm(m, EPI_RESID, true, a);
+    }
 }
 
 // FeedForward.Forward (transformer.go:40-96) up to (not including) the W2 projection:
@@ -828,6 +858,7 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
     md.seq_slot = md.seq_pos + S; md.last_rows = md.seq_slot + S;
     md.tokens = m->meta_dev + 5 * S; md.tok_pos = md.tokens + M; md.tok_slot = md.tok_pos + M;
     NVL_HIP(hipEventRecord(m->ev0, m->stream));
+    m->pending_slices = 0;
     NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, (size_t)(5 * S + 3 * (int64_t)M) * 4, hipMemcpyHostToDevice, m->stream));
 
     if (m->keep_hidden && m->hidden_tokens < M) {
@@ -882,18 +913,17 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
             // generic_model.go:395-418: r + [am*]attn + [rm*]ffn, both branches read the same normed x
             const bool mults = c.attention_multiplier != 0.f && c.residual_multiplier != 0.f;
             ffn_up(m, l, M);
-            gemm(m, EPI_RESID, true, mk(m->attn_out, qw, l.t[NVL_T_WO].p, m->x, H, bo, mults ? c.attention_multiplier : 1.f, M, H, qw));
-            gemm(m, EPI_RESID, true, mk(m->hbuf, m->F, l.t[NVL_T_W2].p, m->x, H, (const float*)l.t[NVL_T_B2].p,
-                                        mults ? c.residual_multiplier : 1.f, M, H, m->F));
+            resid_gemm(m, m->attn_out, qw, l.t[NVL_T_WO].p, bo, mults ? c.attention_multiplier : 1.f, M, H, qw);
+            resid_gemm(m, m->hbuf, m->F, l.t[NVL_T_W2].p, (const float*)l.t[NVL_T_B2].p, mults ? c.residual_multiplier : 1.f,
+                       M, H, m->F);   // (only one of the two may be pending: the second one adds into x directly)
         } else {
-            gemm(m, EPI_RESID, true, mk(m->attn_out, qw, l.t[NVL_T_WO].p, m->x, H, bo, m->resid_alpha, M, H, qw));
+            resid_gemm(m, m->attn_out, qw, l.t[NVL_T_WO].p, bo, m->resid_alpha, M, H, qw);
             norm(m, m->x, nullptr, l.t[NVL_T_FFN_NORM_W], l.t[NVL_T_FFN_NORM_B], m->xn, M);
             if (c.use_moe) {
                 moe(m, l, M);
             } else {
                 ffn_up(m, l, M);
-                gemm(m, EPI_RESID, true, mk(m->hbuf, m->F, l.t[NVL_T_W2].p, m->x, H, (const float*)l.t[NVL_T_B2].p,
-                                            m->resid_alpha, M, H, m->F));
+                resid_gemm(m, m->hbuf, m->F, l.t[NVL_T_W2].p, (const float*)l.t[NVL_T_B2].p, m->resid_alpha, M, H, m->F);
             }
         }
         if (m->keep_hidden)
@@ -911,6 +941,7 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
         m->logit_rows = rows;
     }
     norm(m, m->x, all ? nullptr : md.last_rows, m->g[NVL_T_FINAL_NORM_W], m->g[NVL_T_FINAL_NORM_B], m->xn_last, rows);
+    if (m->pending_slices != 0) throw std::runtime_error("forward: a split-K residual was left unconsumed");
     gemm(m, EPI_STORE, true, mk(m->xn_last, H, m->lm_head, m->logits, m->Vpad, nullptr, 1.f, rows, m->V, H));
     {
         KScope ks(m, KC_OTHER);
