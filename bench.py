@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-prompt", type=int, default=8)
     ap.add_argument("--cpu-gen", type=int, default=4)
+    ap.add_argument("--tp", action="store_true", help="all ranks form ONE tensor-parallel group (RCCL all-reduce) "
+                    "and process the same batch: strong scaling, e.g. --model llama-3-8b --gpus 8 --tp")
     ap.add_argument("--tune", default="", help="nvl_set_tuning overrides, e.g. 1=2 (key=value, comma separated)")
     return ap.parse_args()
 
@@ -159,15 +161,23 @@ def main():
     B, S, G = args.batch, args.prompt, args.gen
     assert S + G <= cfg["max_seq_len"]
     max_batch_tokens = min(B * S, 16384)
+    tp = args.tp
     model = pkg.HipTransformerModel(cfg, None, device=local_rank, precision=args.precision, max_seqs=B,
-                                    max_batch_tokens=max_batch_tokens)
+                                    max_batch_tokens=max_batch_tokens, tp_rank=rank if tp else 0,
+                                    tp_size=world if tp else 1, tp_force_single=tp and world == 1)
     want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
     t0 = time.time()
     host_w = gen_weights_on_device(pkg, cfg, model, torch, device, keep_host=want_cpu)
     model.finalize()
+    if tp:   # rank 0 creates the RCCL unique id, every rank joins (collective)
+        uid = [pkg.HipTransformerModel.tp_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        model.tp_init(uid[0])
     t_load = time.time() - t0
 
-    rng = np.random.default_rng(1234 + 1 + rank)   # seed 1234 + cfg_idx (+rank: own sequences)
+    # seed 1234 + cfg_idx; data parallel: +rank (own sequences); tensor parallel: same batch on all ranks
+    rng = np.random.default_rng(1234 + 1 + (0 if tp else rank))
     prompts = rng.integers(0, cfg["vocab_size"], (B, S)).astype(np.int32)
     seq_ids = list(range(B))
     seqs_per_call = max(1, max_batch_tokens // S)
@@ -218,7 +228,8 @@ def main():
     st = model.stats()
 
     tokens_per_step = B * S + B * G
-    value = world * tokens_per_step * args.steps / elapsed
+    nrep = 1 if tp else world          # tensor parallel: ONE batch for the whole group
+    value = nrep * tokens_per_step * args.steps / elapsed
     body, head = flops_per_token(cfg)
     gemm_tflops = st["gemm_flops"] / (st["gemm_ms"] * 1e-3) / 1e12 if st["gemm_ms"] > 0 else 0.0
     # decode step: every weight byte is read once per step (algorithmic bytes), KV on top
@@ -242,13 +253,13 @@ def main():
     out = {
         "metric": "prefill + decode tokens/sec, Llama-3.2-1B bf16, 1/2/4/8 MI355X",
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong" if tp else "weak",
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic (seeded random weights at the model's "
         "shapes, uniform random token ids)",
         "config": {"workload": f"{args.model}: {B} seqs/GPU x {S} prompt tokens prefill + {G} greedy decode steps",
-                   "batch_per_gpu": B, "prompt_len": S, "gen_len": G, "parallelism": f"dp{world} over sequences"},
-        "prefill_tokens_per_s": round(world * B * S * args.steps / pre_s, 1),
-        "decode_tokens_per_s": round(world * B * G * args.steps / dec_s, 1),
+                   "batch_per_gpu": B, "prompt_len": S, "gen_len": G, "parallelism": (f"tp{world} (column/row-parallel, RCCL all-reduce)" if tp else f"dp{world} over sequences")},
+        "prefill_tokens_per_s": round(nrep * B * S * args.steps / pre_s, 1),
+        "decode_tokens_per_s": round(nrep * B * G * args.steps / dec_s, 1),
         "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (prefill QKV/O/FFN/LM-head projections)",
                      "achieved": round(gemm_tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(gemm_tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,

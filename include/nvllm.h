@@ -75,7 +75,8 @@ typedef struct nvl_runtime_opts {
     int32_t max_batch_tokens;  /* largest sum(seq_lens) one nvl_forward call may carry             */
     int32_t tp_rank, tp_size;  /* tensor-parallel shard of this process (1 = none); consumer of the
                                   reference's inert Config.TensorParallelSize (nanovllm/config.go:61) */
-    int32_t reserved[2];
+    int32_t reserved[2];       /* reserved[0] = 1 with tp_size = 1: diagnostics — run the tensor-parallel
+                                  projection + all-reduce path on a one-rank group (needs nvl_tp_init) */
 } nvl_runtime_opts;
 
 typedef struct nvl_model nvl_model;
@@ -139,6 +140,18 @@ int nvl_finalize(nvl_model* m);
 
 /* Replaces TensorModelRunner.Close (tensor_model_runner.go:114-117). */
 void nvl_destroy(nvl_model* m);
+
+/* ---- tensor parallelism (the reference's Config.TensorParallelSize is inert: nanovllm/config.go:61) ----
+ * A model created with tp_size = T > 1 is rank tp_rank's shard: column-parallel Q/K/V and gate/up, row-parallel O and
+ * down, one all-reduce (sum, fp32) after the O projection and one after the down projection; embeddings, norms and the
+ * LM head are replicated, so every rank produces the same logits and the same greedy token.  Upload the FULL tensors:
+ * each rank keeps its slice.  One process per GPU: rank 0 calls nvl_tp_get_unique_id, ships the 128 bytes to the other
+ * ranks by any channel, and every rank calls nvl_tp_init (collective; RCCL over xGMI) before its first nvl_forward.
+ * nvl_tp_attach_local joins the T shard models of ONE process on ONE device into an emulated group (each driven
+ * from its own host thread) — used to test the sharded arithmetic where only one GPU exists. */
+int nvl_tp_get_unique_id(void* id_out, int bytes);
+int nvl_tp_init(nvl_model* m, const void* id, int bytes);
+int nvl_tp_attach_local(nvl_model** models, int n);
 
 /* ---- sequences: replace map[int64]*KVCache (tensor_model_runner.go:11-18,59-68,100-112) ---- */
 int nvl_seq_open(nvl_model* m, int64_t seq_id);     /* get-or-create a KV slot                     */

@@ -120,6 +120,10 @@ def lib():
     L.nvl_op_argmax.argtypes = [C.c_int, vp, C.c_int, C.c_int, vp]
     L.nvl_bench_gemm.argtypes = [C.c_int] * 8 + [vp]
     L.nvl_set_tuning.argtypes = [C.c_int, C.c_int]
+    L.nvl_tp_get_unique_id.argtypes = [vp, C.c_int]
+    L.nvl_tp_init.argtypes = [vp, vp, C.c_int]
+    L.nvl_tp_attach_local.argtypes = [vp, C.c_int]
+    L.nvl_sizeof.argtypes = [C.c_int]
     _lib = L
     return L
 

@@ -433,34 +433,61 @@ __device__ __forceinline__ float ld_as_f32(const void* p, int dtype, int64_t i) 
     if (dtype == 1) return (float)((const bf16_t*)p)[i];
     return (float)((const _Float16*)p)[i];
 }
-// dst[n][k] (n < N, k < K) from src in IN_OUT ([K][N]) or OUT_IN ([N][K]) order; FM selects the
-// fragment-major destination layout (bf16 MFMA weights), else row-major [N][K].
+// dst rows [dn0, dn0+N) x cols [0, K) of a [.][K] matrix  <-  the sub-block rows [sn0, sn0+N) x cols [sk0, sk0+K)
+// of the logical [SN][SK] source, stored IN_OUT ([SK][SN]) or OUT_IN ([SN][SK]).  The sub-block form is how a
+// tensor-parallel rank takes its shard while the tensor is converted; FM selects the fragment-major
+// destination layout (bf16 MFMA operands), else row-major.
+struct Slice2D { int64_t SN, SK, sn0, sk0, dn0; };
 template <typename DT, bool FM>
 __global__ void convert_2d_kernel(const void* __restrict__ src, int dtype, int transpose_in,
-                                  DT* __restrict__ dst, int64_t N, int64_t K) {
+                                  DT* __restrict__ dst, int64_t N, int64_t K, Slice2D sl) {
     __shared__ float tile[32][33];
     const int64_t n0 = (int64_t)blockIdx.y * 32, k0 = (int64_t)blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
     if (transpose_in) {
         for (int r = ty; r < 32; r += 8) {
             const int64_t k = k0 + r, n = n0 + tx;
-            tile[r][tx] = (k < K && n < N) ? ld_as_f32(src, dtype, k * N + n) : 0.f;
+            tile[r][tx] = (k < K && n < N) ? ld_as_f32(src, dtype, (sl.sk0 + k) * sl.SN + sl.sn0 + n) : 0.f;
         }
         __syncthreads();
         for (int r = ty; r < 32; r += 8) {
             const int64_t n = n0 + r, k = k0 + tx;
-            if (n < N && k < K) dst[FM ? fm_index(n, k, K) : n * K + k] = (DT)tile[tx][r];
+            if (n < N && k < K) dst[FM ? fm_index(sl.dn0 + n, k, K) : (sl.dn0 + n) * K + k] = (DT)tile[tx][r];
         }
     } else {
         for (int r = ty; r < 32; r += 8) {
             const int64_t n = n0 + r, k = k0 + tx;
-            if (n < N && k < K) dst[FM ? fm_index(n, k, K) : n * K + k] = (DT)ld_as_f32(src, dtype, n * K + k);
+            if (n < N && k < K)
+                dst[FM ? fm_index(sl.dn0 + n, k, K) : (sl.dn0 + n) * K + k] =
+                    (DT)ld_as_f32(src, dtype, (sl.sn0 + n) * sl.SK + sl.sk0 + k);
         }
     }
 }
-__global__ void convert_1d_kernel(const void* __restrict__ src, int dtype, float* __restrict__ dst, int64_t n) {
+__global__ void convert_1d_kernel(const void* __restrict__ src, int dtype, float* __restrict__ dst, int64_t n,
+                                  int64_t src_off) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = ld_as_f32(src, dtype, i);
+    if (i < n) dst[i] = ld_as_f32(src, dtype, src_off + i);
+}
+
+// tensor parallel: x[m][:] += alpha * (part[m][:] (+ bias))  after the all-reduce of a row-parallel projection
+__global__ void axpy_rows_kernel(float* __restrict__ x, const float* __restrict__ part, const float* __restrict__ bias,
+                                 float alpha, int64_t rows, int H) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= rows * H) return;
+    f32x4 v = *(const f32x4*)(part + i);
+    if (bias) v += *(const f32x4*)(bias + (i % H));
+    f32x4 o = *(f32x4*)(x + i);
+    o += alpha * v;
+    *(f32x4*)(x + i) = o;
+}
+// local tensor-parallel emulation (several shard models of one process on one GPU): dst = sum_r src[r]
+struct PtrList8 { const float* p[8]; };
+__global__ void sum_bufs_kernel(float* __restrict__ dst, PtrList8 srcs, int n_src, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 s = *(const f32x4*)(srcs.p[0] + i);
+    for (int r = 1; r < n_src; r++) s += *(const f32x4*)(srcs.p[r] + i);
+    *(f32x4*)(dst + i) = s;
 }
 // dst row r (of K elements) = src row idx[r], or zeros when idx[r] < 0
 template <typename DT>

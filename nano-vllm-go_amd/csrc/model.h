@@ -1,7 +1,9 @@
 // model.h — host-side state of one nvl_model handle (device weights in kernel layout, KV slabs,
 // workspaces, the HIP stream) and the kernel launch helpers shared by nvllm.hip and ops.hip.
 #pragma once
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,6 +35,17 @@ struct ProfRec { hipEvent_t a, b; int cls; double flops; };
 
 }  // namespace nvl
 
+// in-process tensor-parallel group (tests on one GPU): see tp_allreduce in nvllm.hip
+struct nvl_local_group {
+    std::mutex mu;
+    std::condition_variable cv;
+    int n = 0, arrived = 0, refs = 0;
+    uint64_t gen = 0;
+    float* bufs[8] = {nullptr};
+    float* scratch = nullptr;
+    int64_t scratch_floats = 0;
+};
+
 struct nvl_model {
     nvl_model_config cfg{};
     nvl_runtime_opts opts{};
@@ -42,8 +55,13 @@ struct nvl_model {
     hipStream_t stream = nullptr;
     std::string err;
 
-    // derived
+    // derived (nH, nKV, F are the LOCAL sizes of this tensor-parallel rank; *_full the model's)
     int H = 0, nH = 0, nKV = 0, hd = 0, F = 0, V = 0, Vpad = 0, L = 0, group = 1;
+    int tp = 1, tp_rank = 0, nH_full = 0, nKV_full = 0, F_full = 0;
+    bool tp_force = false;
+    void* tp_comm = nullptr;          // ncclComm_t
+    nvl_local_group* tp_local = nullptr;   // in-process emulation (tests on one GPU)
+    float* tp_part = nullptr;         // [Mmax][H] fp32 partial of a row-parallel projection
     int n_qkv = 0, Tmax = 0;
     float attn_scale = 0.f, resid_alpha = 1.f;
     size_t wsize = 2;            // bytes per weight/activation element
@@ -79,7 +97,7 @@ struct nvl_model {
     float* moe_eo = nullptr;          // [Mmax*k][H]
     int32_t *moe_counts = nullptr, *moe_cursor = nullptr, *moe_tile_map = nullptr, *moe_n_mtiles = nullptr;
     // decode split-K: partial slices of the last residual GEMM, consumed by the next norm launch
-    float* sk_part = nullptr; int sk_max_slices = 4; int pending_slices = 0, pending_rows = 0; float pending_alpha = 1.f;
+    float* sk_part = nullptr; int sk_max_slices = 4; int pending_slices = 0, pending_rows = 0; float pending_alpha = 1.f; const float* pending_part = nullptr;
     // per-call metadata (one pinned host block mirrored on the device)
     int32_t* meta_host = nullptr; int32_t* meta_dev = nullptr; int64_t meta_ints = 0;
     // debug

@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstring>
 
+#include <rccl/rccl.h>
+
 #include "model.h"
 
 using namespace nvl;
@@ -156,8 +158,16 @@ extern "C" int nvl_create(const nvl_model_config* cfg, const nvl_runtime_opts* o
         return fail(nullptr, NVL_ERR_INVALID, "nvl_create: head_dim must be 64 or 128");
     if (c.hidden % 64 != 0 || (c.ffn_dim % 64) != 0)
         return fail(nullptr, NVL_ERR_INVALID, "nvl_create: hidden and ffn_dim must be multiples of 64");
-    if (opts->tp_size > 1)
-        return fail(nullptr, NVL_ERR_INVALID, "nvl_create: tensor parallel shards are not implemented yet");
+    const int tp = opts->tp_size > 1 ? opts->tp_size : 1;
+    if (tp > 1) {
+        const int nkv_full = c.attention_type == NVL_ATTN_MHA ? c.num_heads : c.num_kv_heads;
+        if (opts->tp_rank < 0 || opts->tp_rank >= tp || tp > 8)
+            return fail(nullptr, NVL_ERR_INVALID, "nvl_create: tp_rank/tp_size out of range (tp_size <= 8)");
+        if (c.attention_type == NVL_ATTN_MQA || c.use_moe)
+            return fail(nullptr, NVL_ERR_INVALID, "nvl_create: tensor parallelism covers MHA/GQA dense models (MQA has one KV head; MoE shards by expert)");
+        if (c.num_heads % tp || nkv_full % tp || c.ffn_dim % (tp * 64))
+            return fail(nullptr, NVL_ERR_INVALID, "nvl_create: heads, kv heads and ffn_dim/64 must divide by tp_size");
+    }
     nvl_model* m = new nvl_model();
     NVL_TRY(m)
     m->cfg = c; m->opts = *opts;
@@ -172,6 +182,13 @@ extern "C" int nvl_create(const nvl_model_config* cfg, const nvl_runtime_opts* o
     m->L = c.num_layers;
     m->nKV = c.attention_type == NVL_ATTN_MHA ? c.num_heads : (c.attention_type == NVL_ATTN_MQA ? 1 : c.num_kv_heads);
     if (m->nKV <= 0 || m->nH % m->nKV != 0) throw std::runtime_error("num_heads must be a multiple of num_kv_heads");
+    // tensor parallel shard: this rank owns nH/tp query heads, nKV/tp kv heads and F/tp FFN
+    // columns; from here on nH / nKV / F are the LOCAL sizes (hidden H, vocab V stay full: residual stream,
+    // norms, embeddings and the LM head are replicated)
+    m->tp = tp; m->tp_rank = tp > 1 ? opts->tp_rank : 0;
+    m->tp_force = tp == 1 && opts->reserved[0] == 1;   // diagnostics: run the row-parallel path + all-reduce with one rank
+    m->nH_full = m->nH; m->nKV_full = m->nKV; m->F_full = m->F;
+    m->nH /= tp; m->nKV /= tp; m->F /= tp;
     m->group = m->nH / m->nKV;
     m->Vpad = (int)round_up(m->V, 128);
     m->n_qkv = (m->nH + 2 * m->nKV) * m->hd;
@@ -210,7 +227,13 @@ extern "C" void nvl_destroy(nvl_model* m) {
     dfree(m->x); dfree(m->xn); dfree(m->qkv); dfree(m->q); dfree(m->attn_out); dfree(m->hbuf); dfree(m->h2);
     dfree(m->xn_last); dfree(m->logits); dfree(m->argmax_dev); dfree(m->argmax_pval); dfree(m->argmax_pidx); dfree(m->router_logits); dfree(m->expert_ids);
     dfree(m->expert_w); dfree(m->seg_start); dfree(m->moe_counts); dfree(m->moe_cursor); dfree(m->moe_tile_map); dfree(m->moe_n_mtiles); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo);
-    dfree(m->meta_dev); dfree(m->hidden); dfree(m->sk_part);
+    dfree(m->meta_dev); dfree(m->hidden); dfree(m->sk_part); dfree(m->tp_part);
+    if (m->tp_comm) (void)ncclCommDestroy((ncclComm_t)m->tp_comm);
+    if (m->tp_local) {
+        bool last;
+        { std::lock_guard<std::mutex> lk(m->tp_local->mu); last = --m->tp_local->refs == 0; }
+        if (last) { dfree(m->tp_local->scratch); delete m->tp_local; }
+    }
     if (m->meta_host) (void)hipHostFree(m->meta_host);
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
@@ -224,36 +247,42 @@ extern "C" void nvl_destroy(nvl_model* m) {
 // =================================================================================================
 namespace {
 
-// canonical device copy: 2-D -> [rows_pad(W_ROW_PAD)][K] in weight dtype; 1-D -> fp32
-void upload_2d(nvl_model* m, DevTensor* t, const void* data, int dtype, int64_t N, int64_t K, bool src_is_in_out) {
+// canonical device copy: 2-D -> [rows_pad(W_ROW_PAD)][K] in weight dtype; 1-D -> fp32.
+// `sl` selects the sub-block of the uploaded tensor that lands in rows [dn0, dn0+N) (the whole tensor for
+// replicated kinds, this rank's shard for tensor-parallel kinds); total_rows sizes the destination.
+void upload_2d(nvl_model* m, DevTensor* t, const void* data, int dtype, int64_t N, int64_t K, bool src_is_in_out,
+               Slice2D sl, int64_t total_rows, bool first_piece) {
     const size_t esz = dtype == NVL_DTYPE_F32 ? 4 : 2;
-    void* raw = dmalloc_bytes((int64_t)N * K * esz);
-    NVL_HIP(hipMemcpyAsync(raw, data, (size_t)N * K * esz, hipMemcpyDefault, m->stream));
-    const int64_t Npad = round_up(N, W_ROW_PAD);
-    dfree(t->p);
-    t->p = dmalloc_bytes(Npad * K * (int64_t)m->wsize);
-    NVL_HIP(hipMemsetAsync(t->p, 0, (size_t)(Npad * K) * m->wsize, m->stream));
+    const int64_t src_elems = sl.SN * sl.SK;
+    void* raw = dmalloc_bytes(src_elems * (int64_t)esz);
+    NVL_HIP(hipMemcpyAsync(raw, data, (size_t)src_elems * esz, hipMemcpyDefault, m->stream));
+    const int64_t Npad = round_up(total_rows, W_ROW_PAD);
+    if (first_piece) {
+        dfree(t->p);
+        t->p = dmalloc_bytes(Npad * K * (int64_t)m->wsize);
+        NVL_HIP(hipMemsetAsync(t->p, 0, (size_t)(Npad * K) * m->wsize, m->stream));
+        m->stats.weight_bytes += (double)Npad * K * m->wsize;
+    }
     dim3 grid((unsigned)cdiv(K, 32), (unsigned)cdiv(N, 32));
     if (m->f32)
         hipLaunchKernelGGL((convert_2d_kernel<float, false>), grid, dim3(256), 0, m->stream, raw, dtype,
-                           src_is_in_out ? 1 : 0, (float*)t->p, N, K);
+                           src_is_in_out ? 1 : 0, (float*)t->p, N, K, sl);
     else   // bf16 weights (and the embedding tables) live in the fragment-major layout
         hipLaunchKernelGGL((convert_2d_kernel<bf16_t, true>), grid, dim3(256), 0, m->stream, raw, dtype,
-                           src_is_in_out ? 1 : 0, (bf16_t*)t->p, N, K);
+                           src_is_in_out ? 1 : 0, (bf16_t*)t->p, N, K, sl);
     NVL_HIP(hipGetLastError());
     NVL_HIP(hipStreamSynchronize(m->stream));
     dfree(raw);
-    t->rows = N; t->cols = K; t->rows_pad = Npad;
-    m->stats.weight_bytes += (double)Npad * K * m->wsize;
+    t->rows = total_rows; t->cols = K; t->rows_pad = Npad;
 }
 
-void upload_1d(nvl_model* m, DevTensor* t, const void* data, int dtype, int64_t n) {
+void upload_1d(nvl_model* m, DevTensor* t, const void* data, int dtype, int64_t n_src, int64_t off, int64_t n) {
     const size_t esz = dtype == NVL_DTYPE_F32 ? 4 : 2;
-    void* raw = dmalloc_bytes(n * (int64_t)esz);
-    NVL_HIP(hipMemcpyAsync(raw, data, (size_t)n * esz, hipMemcpyDefault, m->stream));
+    void* raw = dmalloc_bytes(n_src * (int64_t)esz);
+    NVL_HIP(hipMemcpyAsync(raw, data, (size_t)n_src * esz, hipMemcpyDefault, m->stream));
     dfree(t->p);
     t->p = dmalloc<float>(n);
-    hipLaunchKernelGGL(convert_1d_kernel, dim3(cdiv(n, 256)), dim3(256), 0, m->stream, raw, dtype, (float*)t->p, n);
+    hipLaunchKernelGGL(convert_1d_kernel, dim3(cdiv(n, 256)), dim3(256), 0, m->stream, raw, dtype, (float*)t->p, n, off);
     NVL_HIP(hipGetLastError());
     NVL_HIP(hipStreamSynchronize(m->stream));
     dfree(raw);
@@ -261,23 +290,24 @@ void upload_1d(nvl_model* m, DevTensor* t, const void* data, int dtype, int64_t 
     m->stats.weight_bytes += (double)n * 4;
 }
 
-int64_t expect_out(const nvl_model* m, int kind) {   // logical N (out features) per kind
+// FULL (unsharded) logical sizes of a 2-D weight kind, as the host holds it
+int64_t full_out(const nvl_model* m, int kind) {
     switch (kind) {
         case NVL_T_LM_HEAD: return m->V;
-        case NVL_T_WQ: return (int64_t)m->nH * m->hd;
-        case NVL_T_WK: case NVL_T_WV: return (int64_t)m->nKV * m->hd;
+        case NVL_T_WQ: return (int64_t)m->nH_full * m->hd;
+        case NVL_T_WK: case NVL_T_WV: return (int64_t)m->nKV_full * m->hd;
         case NVL_T_WKV: return 2 * m->hd;
         case NVL_T_WO: return m->H;
-        case NVL_T_W1: return m->cfg.activation_type == NVL_ACT_SWIGLU ? 2 * (int64_t)m->F : m->F;
+        case NVL_T_W1: return m->cfg.activation_type == NVL_ACT_SWIGLU ? 2 * (int64_t)m->F_full : m->F_full;
         case NVL_T_W2: return m->H;
         case NVL_T_ROUTER: return m->cfg.num_experts;
         default: return -1;
     }
 }
-int64_t expect_in(const nvl_model* m, int kind) {
+int64_t full_in(const nvl_model* m, int kind) {
     switch (kind) {
-        case NVL_T_WO: return (int64_t)m->nH * m->hd;
-        case NVL_T_W2: return m->F;
+        case NVL_T_WO: return (int64_t)m->nH_full * m->hd;
+        case NVL_T_W2: return m->F_full;
         default: return m->H;
     }
 }
@@ -294,9 +324,18 @@ extern "C" int nvl_upload_tensor(nvl_model* m, int kind, int layer, const void* 
     NVL_TRY(m)
     NVL_HIP(hipSetDevice(m->device));
     char buf[256];
+    const int r = m->tp_rank;
     if (is_1d(kind)) {
         const int64_t n = rows * (cols > 0 ? cols : 1);
-        upload_1d(m, t, data, dtype, n);
+        int64_t off = 0, cnt = n;
+        if (m->tp > 1) {   // column-parallel biases follow their projection's shard; row-parallel biases stay on rank 0
+            if (kind == NVL_T_BQ) { cnt = (int64_t)m->nH * m->hd; off = r * cnt; }
+            else if (kind == NVL_T_BK || kind == NVL_T_BV) { cnt = (int64_t)m->nKV * m->hd; off = r * cnt; }
+            else if (kind == NVL_T_B1) { cnt = m->F; off = r * cnt; }
+            else if ((kind == NVL_T_BO || kind == NVL_T_B2) && r != 0) return NVL_OK;
+            if (off + cnt > n) return fail(m, NVL_ERR_INVALID, "nvl_upload_tensor: bias shorter than the full (unsharded) size");
+        }
+        upload_1d(m, t, data, dtype, n, off, cnt);
         return NVL_OK;
     }
     if (kind == NVL_T_TOK_EMB || kind == NVL_T_POS_EMB) {
@@ -306,7 +345,7 @@ extern "C" int nvl_upload_tensor(nvl_model* m, int kind, int layer, const void* 
                      (long long)cols, (long long)want_rows, m->H);
             return fail(m, NVL_ERR_INVALID, buf);
         }
-        upload_2d(m, t, data, dtype, rows, cols, false);
+        upload_2d(m, t, data, dtype, rows, cols, false, Slice2D{rows, cols, 0, 0, 0}, rows, true);
         return NVL_OK;
     }
     if (kind == NVL_T_MOE_IN || kind == NVL_T_MOE_OUT) {
@@ -318,19 +357,45 @@ extern "C" int nvl_upload_tensor(nvl_model* m, int kind, int layer, const void* 
                      (long long)cols, (long long)out, (long long)in);
             return fail(m, NVL_ERR_INVALID, buf);
         }
-        upload_2d(m, t, data, dtype, rows, cols, false);
+        upload_2d(m, t, data, dtype, rows, cols, false, Slice2D{rows, cols, 0, 0, 0}, rows, true);
         return NVL_OK;
     }
-    const int64_t N = expect_out(m, kind), K = expect_in(m, kind);
-    if (N < 0) return fail(m, NVL_ERR_INVALID, "nvl_upload_tensor: kind is not a 2-D weight");
+    const int64_t SN = full_out(m, kind), SK = full_in(m, kind);
+    if (SN < 0) return fail(m, NVL_ERR_INVALID, "nvl_upload_tensor: kind is not a 2-D weight");
     const int64_t got_in = layout == NVL_LAYOUT_IN_OUT ? rows : cols;
     const int64_t got_out = layout == NVL_LAYOUT_IN_OUT ? cols : rows;
-    if (got_in != K || got_out != N) {   // reference: panic "incompatible shapes" tensor.go:67
+    if (got_in != SK || got_out != SN) {   // reference: panic "incompatible shapes" tensor.go:67
         snprintf(buf, sizeof buf, "weight kind %d: got [in=%lld,out=%lld], model needs [in=%lld,out=%lld]", kind,
-                 (long long)got_in, (long long)got_out, (long long)K, (long long)N);
+                 (long long)got_in, (long long)got_out, (long long)SK, (long long)SN);
         return fail(m, NVL_ERR_INVALID, buf);
     }
-    upload_2d(m, t, data, dtype, N, K, layout == NVL_LAYOUT_IN_OUT);
+    const bool io = layout == NVL_LAYOUT_IN_OUT;
+    if (m->tp == 1) {
+        upload_2d(m, t, data, dtype, SN, SK, io, Slice2D{SN, SK, 0, 0, 0}, SN, true);
+        return NVL_OK;
+    }
+    // ---- tensor-parallel shard of the uploaded FULL tensor ----
+    const int64_t hd = m->hd;
+    switch (kind) {
+        case NVL_T_WQ: { const int64_t nl = m->nH * hd;     // column parallel: this rank's query heads
+            upload_2d(m, t, data, dtype, nl, SK, io, Slice2D{SN, SK, r * nl, 0, 0}, nl, true); break; }
+        case NVL_T_WK: case NVL_T_WV: { const int64_t nl = m->nKV * hd;
+            upload_2d(m, t, data, dtype, nl, SK, io, Slice2D{SN, SK, r * nl, 0, 0}, nl, true); break; }
+        case NVL_T_WO: { const int64_t kl = m->nH * hd;     // row parallel: K slice = this rank's heads
+            upload_2d(m, t, data, dtype, SN, kl, io, Slice2D{SN, SK, 0, r * kl, 0}, SN, true); break; }
+        case NVL_T_W1: { const int64_t fl = m->F;
+            if (m->cfg.activation_type == NVL_ACT_SWIGLU) {   // [gate F | up F] -> [gate_loc | up_loc]
+                upload_2d(m, t, data, dtype, fl, SK, io, Slice2D{SN, SK, r * fl, 0, 0}, 2 * fl, true);
+                upload_2d(m, t, data, dtype, fl, SK, io, Slice2D{SN, SK, m->F_full + r * fl, 0, fl}, 2 * fl, false);
+            } else {
+                upload_2d(m, t, data, dtype, fl, SK, io, Slice2D{SN, SK, r * fl, 0, 0}, fl, true);
+            }
+            break; }
+        case NVL_T_W2: { const int64_t kl = m->F;           // row parallel
+            upload_2d(m, t, data, dtype, SN, kl, io, Slice2D{SN, SK, 0, r * kl, 0}, SN, true); break; }
+        default:                                            // LM head etc.: replicated
+            upload_2d(m, t, data, dtype, SN, SK, io, Slice2D{SN, SK, 0, 0, 0}, SN, true);
+    }
     return NVL_OK;
     NVL_CATCH(m)
 }
@@ -567,6 +632,7 @@ extern "C" int nvl_finalize(nvl_model* m) {
         m->moe_eo = dmalloc<float>(Mmax * k * H);
     }
     if (!m->f32) m->sk_part = dmalloc<float>((int64_t)m->sk_max_slices * 64 * H);
+    if (m->tp > 1 || m->tp_force) m->tp_part = dmalloc<float>(Mmax * H);
     m->meta_ints = 3 * Mmax + 5 * S + 16;
     NVL_HIP(hipHostMalloc((void**)&m->meta_host, (size_t)m->meta_ints * 4, hipHostMallocDefault));
     m->meta_dev = dmalloc<int32_t>(m->meta_ints);
@@ -574,6 +640,56 @@ extern "C" int nvl_finalize(nvl_model* m) {
     m->finalized = true;
     return NVL_OK;
     NVL_CATCH(m)
+}
+
+// =================================================================================================
+// tensor parallel group
+// =================================================================================================
+extern "C" int nvl_tp_get_unique_id(void* id_out, int bytes) {
+    if (!id_out || bytes < (int)sizeof(ncclUniqueId)) return fail(nullptr, NVL_ERR_INVALID, "nvl_tp_get_unique_id: need a 128-byte buffer");
+    ncclUniqueId id;
+    const ncclResult_t rc = ncclGetUniqueId(&id);
+    if (rc != ncclSuccess) return fail(nullptr, NVL_ERR_HIP, std::string("ncclGetUniqueId: ") + ncclGetErrorString(rc));
+    memcpy(id_out, &id, sizeof id);
+    return NVL_OK;
+}
+extern "C" int nvl_tp_init(nvl_model* m, const void* id_in, int bytes) {
+    if (!m || !id_in || bytes < (int)sizeof(ncclUniqueId)) return fail(m, NVL_ERR_INVALID, "nvl_tp_init: bad arguments");
+    if (m->tp_comm || m->tp_local) return fail(m, NVL_ERR_STATE, "nvl_tp_init: a group is already attached");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof id);
+    ncclComm_t comm;
+    const ncclResult_t rc = ncclCommInitRank(&comm, m->tp, id, m->tp_rank);
+    if (rc != ncclSuccess) return fail(m, NVL_ERR_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(rc));
+    m->tp_comm = comm;
+    return NVL_OK;
+    NVL_CATCH(m)
+}
+extern "C" int nvl_tp_attach_local(nvl_model** models, int n) {
+    if (!models || n < 1 || n > 8) return fail(nullptr, NVL_ERR_INVALID, "nvl_tp_attach_local: bad arguments");
+    bool seen[8] = {false};
+    int64_t need = 0;
+    for (int i = 0; i < n; i++) {
+        nvl_model* m = models[i];
+        if (!m || m->tp != n || m->tp_rank < 0 || m->tp_rank >= n || seen[m->tp_rank] || m->tp_comm || m->tp_local ||
+            m->device != models[0]->device)
+            return fail(nullptr, NVL_ERR_INVALID, "nvl_tp_attach_local: members must be the n distinct ranks of one tp_size = n group on one device");
+        seen[m->tp_rank] = true;
+        need = std::max<int64_t>(need, (int64_t)m->opts.max_batch_tokens * m->H);
+    }
+    try {
+        nvl_local_group* g = new nvl_local_group();
+        g->n = n; g->refs = n;
+        NVL_HIP(hipSetDevice(models[0]->device));
+        g->scratch = dmalloc<float>(need);
+        g->scratch_floats = need;
+        for (int i = 0; i < n; i++) models[i]->tp_local = g;
+        return NVL_OK;
+    } catch (const HipError& e) {
+        return fail(nullptr, NVL_ERR_HIP, hipGetErrorString(e.code));
+    }
 }
 
 // =================================================================================================
@@ -629,7 +745,7 @@ void launch_norm(nvl_model* m, float* x, const int32_t* rows_idx, const float* w
     KScope ks(m, KC_OTHER);
     PendingResid pr{nullptr, 0, 0, 0.f};
     if (m->pending_slices > 0) {            // complete the residual add the previous decode GEMM left as split-K slices
-        pr.part = m->sk_part; pr.slices = m->pending_slices; pr.rows_total = m->pending_rows; pr.alpha = m->pending_alpha;
+        pr.part = m->pending_part; pr.slices = m->pending_slices; pr.rows_total = m->pending_rows; pr.alpha = m->pending_alpha;
         m->pending_slices = 0;
         if (!(rows <= 512 && m->H <= 1024 * NORM_ROW_MAXCH)) throw std::runtime_error("norm: pending residual needs the row kernel");
     }
@@ -706,12 +822,60 @@ GemmArgs mk(const void* A, int lda, const void* W, void* C, int ldc, const float
     return a;
 }
 
+// ---- tensor-parallel all-reduce (sum) of a row-parallel projection's fp32 partial -----------------------
+// Real runs: one process per GPU, RCCL over xGMI (nvl_tp_init).  Tests on one GPU: the shard models of a
+// process form a local group (nvl_tp_attach_local) and are driven from one host thread each; the last
+// thread to arrive sums every member's buffer on the device and hands the result back to all of them.
+void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
+    KScope ks(m, KC_OTHER);
+    if (m->tp_comm) {
+        const ncclResult_t rc = ncclAllReduce(buf, buf, (size_t)count, ncclFloat, ncclSum, (ncclComm_t)m->tp_comm, m->stream);
+        if (rc != ncclSuccess) throw std::runtime_error(std::string("ncclAllReduce: ") + ncclGetErrorString(rc));
+        return;
+    }
+    nvl_local_group* g = m->tp_local;
+    if (!g) throw std::runtime_error("tp_size > 1 but no communicator: call nvl_tp_init (RCCL) or nvl_tp_attach_local first");
+    NVL_HIP(hipStreamSynchronize(m->stream));                 // this rank's partial is complete
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (count > g->scratch_floats) throw std::runtime_error("tp local group: scratch too small");
+    g->bufs[m->tp_rank] = buf;
+    const uint64_t my_gen = g->gen;
+    if (++g->arrived == g->n) {
+        PtrList8 pl{};
+        for (int r = 0; r < g->n; r++) pl.p[r] = g->bufs[r];
+        hipLaunchKernelGGL(sum_bufs_kernel, dim3(cdiv(count, 1024)), dim3(256), 0, m->stream, g->scratch, pl, g->n, count);
+        for (int r = 0; r < g->n; r++)
+            NVL_HIP(hipMemcpyAsync(g->bufs[r], g->scratch, (size_t)count * 4, hipMemcpyDeviceToDevice, m->stream));
+        NVL_HIP(hipStreamSynchronize(m->stream));
+        g->arrived = 0;
+        g->gen++;
+        g->cv.notify_all();
+    } else {
+        g->cv.wait(lk, [&] { return g->gen != my_gen; });
+    }
+}
+
 // Residual projection (O projection / W2): x += alpha * (A·W^T + bias)   (generic_model.go:320-326,383-389).
 // Prefill and the fp32 mode fuse the add into the GEMM epilogue.  Decode-sized batches split K over
 // `slices` workgroups per column block so that all 256 CUs stream weights (a 2048-column projection has
 // only 128 column blocks), and leave the add to the norm kernel that always follows (PendingResid).
 static int g_sk_slices = 0;    // tuning override (nvl_set_tuning key 1): 0 automatic, 1 = never split
 void resid_gemm(nvl_model* m, const void* A, int lda, const void* W, const float* bias, float alpha, int M, int N, int K) {
+    if (m->tp > 1 || m->tp_force) {
+        // row-parallel projection: this rank holds a K slice -> fp32 partial [M][N] (the bias lives on rank 0 only),
+        // all-reduce over the tensor-parallel group, then the residual add (folded into the next norm for decode)
+        gemm(m, EPI_STORE, true, mk(A, lda, W, m->tp_part, N, bias, 1.f, M, N, K));
+        tp_allreduce(m, m->tp_part, (int64_t)M * N);
+        if (!m->f32 && M <= 64 && !m->keep_hidden && m->pending_slices == 0) {
+            m->pending_part = m->tp_part; m->pending_slices = 1; m->pending_rows = M; m->pending_alpha = alpha;
+        } else {
+            KScope ks(m, KC_OTHER);
+            hipLaunchKernelGGL(axpy_rows_kernel, dim3(cdiv((int64_t)M * N / 4, 256)), dim3(256), 0, m->stream, m->x,
+                               m->tp_part, (const float*)nullptr, alpha, (int64_t)M, N);
+            NVL_HIP(hipGetLastError());
+        }
+        return;
+    }
     GemmArgs a = mk(A, lda, W, m->x, N, bias, alpha, M, N, K);
     int slices = 1;
     if (!m->f32 && M <= 64 && !m->keep_hidden && m->sk_part && m->pending_slices == 0 && N % 16 == 0) {
@@ -722,7 +886,7 @@ void resid_gemm(nvl_model* m, const void* A, int lda, const void* W, const float
     if (slices > 1) {
         a.sk_part = m->sk_part; a.sk_slices = slices;
         gemm(m, EPI_RESID, true, a);
-        m->pending_slices = slices; m->pending_rows = M; m->pending_alpha = alpha;
+        m->pending_part = m->sk_part; m->pending_slices = slices; m->pending_rows = M; m->pending_alpha = alpha;
     } else {
         gemm(m, EPI_RESID, true, a);
     }

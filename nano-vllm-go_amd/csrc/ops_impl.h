@@ -37,9 +37,9 @@ struct OpCtx {   // a model-less nvl_model carrying just a stream and the fields
         void* d = alloc(Np * K * (int64_t)m.wsize);
         NVL_HIP(hipMemsetAsync(d, 0, (size_t)(Np * K) * m.wsize, m.stream));
         dim3 grid((unsigned)cdiv(K, 32), (unsigned)cdiv(N, 32));
-        if (m.f32) hipLaunchKernelGGL((convert_2d_kernel<float, false>), grid, dim3(256), 0, m.stream, raw, 0, in_out ? 1 : 0, (float*)d, N, K);
-        else if (weight) hipLaunchKernelGGL((convert_2d_kernel<bf16_t, true>), grid, dim3(256), 0, m.stream, raw, 0, in_out ? 1 : 0, (bf16_t*)d, N, K);
-        else hipLaunchKernelGGL((convert_2d_kernel<bf16_t, false>), grid, dim3(256), 0, m.stream, raw, 0, in_out ? 1 : 0, (bf16_t*)d, N, K);
+        if (m.f32) hipLaunchKernelGGL((convert_2d_kernel<float, false>), grid, dim3(256), 0, m.stream, raw, 0, in_out ? 1 : 0, (float*)d, N, K, Slice2D{N, K, 0, 0, 0});
+        else if (weight) hipLaunchKernelGGL((convert_2d_kernel<bf16_t, true>), grid, dim3(256), 0, m.stream, raw, 0, in_out ? 1 : 0, (bf16_t*)d, N, K, Slice2D{N, K, 0, 0, 0});
+        else hipLaunchKernelGGL((convert_2d_kernel<bf16_t, false>), grid, dim3(256), 0, m.stream, raw, 0, in_out ? 1 : 0, (bf16_t*)d, N, K, Slice2D{N, K, 0, 0, 0});
         NVL_HIP(hipGetLastError());
         return d;
     }

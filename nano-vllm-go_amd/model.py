@@ -39,13 +39,18 @@ class HipTransformerModel:
     host or device) — torch device tensors are handed over by pointer with no host copy."""
 
     def __init__(self, cfg: dict, tensors: dict | None, *, device: int = 0, precision: str = "bf16",
-                 max_seqs: int = 8, max_batch_tokens: int | None = None):
-        """tensors=None defers finalize(): upload() each tensor, then call finalize()."""
+                 max_seqs: int = 8, max_batch_tokens: int | None = None, tp_rank: int = 0, tp_size: int = 1,
+                 tp_force_single: bool = False):
+        """tensors=None defers finalize(): upload() each tensor, then call finalize().
+        tp_size > 1 makes this the tp_rank-th tensor-parallel shard: pass the FULL tensors, the library keeps
+        its slice; join the shards with tp_init (RCCL, one process per GPU) or attach_local_group (tests)."""
         self.cfg = dict(cfg)
         self.lib = L.lib()
         self.h = C.c_void_p()
         opts = L.RuntimeOptsC(device=device, precision=L.PRECISION[precision], max_seqs=max_seqs,
-                              max_batch_tokens=max_batch_tokens or cfg["max_seq_len"], tp_rank=0, tp_size=1)
+                              max_batch_tokens=max_batch_tokens or cfg["max_seq_len"], tp_rank=tp_rank, tp_size=tp_size)
+        if tp_force_single:
+            opts.reserved[0] = 1
         self._c = _cfg_struct(cfg)
         L.check(self.lib.nvl_create(C.byref(self._c), C.byref(opts), C.byref(self.h)))
         self.V = cfg["vocab_size"]
@@ -57,6 +62,21 @@ class HipTransformerModel:
 
     def finalize(self):
         L.check(self.lib.nvl_finalize(self.h), self.h)
+
+    # -- tensor parallel group ---------------------------------------------------------------------
+    @staticmethod
+    def tp_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        L.check(L.lib().nvl_tp_get_unique_id(buf, 128))
+        return buf.raw
+
+    def tp_init(self, unique_id: bytes):
+        L.check(self.lib.nvl_tp_init(self.h, C.c_char_p(unique_id), len(unique_id)), self.h)
+
+    @staticmethod
+    def attach_local_group(models):
+        arr = (C.c_void_p * len(models))(*[m.h.value for m in models])
+        L.check(L.lib().nvl_tp_attach_local(arr, len(models)))
 
     # -- weights -----------------------------------------------------------------------------
     def upload(self, slot: str, layer: int, arr, layout: int = L.LAYOUT_IN_OUT):

@@ -1,0 +1,99 @@
+"""Tensor parallelism on ONE GPU: the T shard models of a group live in one process, are driven
+from one host thread each, and all-reduce through the library's local group (nvl_tp_attach_local) — the same
+forward code as the RCCL path, with the collective emulated.  Checks the sharded arithmetic (column-parallel
+Q/K/V/gate/up, row-parallel O/down, one all-reduce after each) against the un-sharded CPU oracle, and that every
+rank returns the same logits / greedy tokens."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = {"f32": 1e-4, "bf16": 1.5e-2}
+
+
+def run_group(models, fn):
+    out, err = [None] * len(models), [None] * len(models)
+
+    def work(i):
+        try:
+            out[i] = fn(models[i])
+        except Exception as e:   # noqa: BLE001
+            err[i] = e
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(models))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not any(t.is_alive() for t in th), "a tensor-parallel rank hung"
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("family,tp", [("llama", 2), ("gpt2", 2), ("llama", 4)])
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_tp_shards_match_unsharded_oracle(gpu, oracle, family, tp, precision):
+    over = dict(num_heads=4, num_kv_heads=4, hidden=256, ffn_dim=512) if (family, tp) == ("llama", 4) else {}
+    cfg = gpu.synth.tiny_config(family, **over)
+    w = gpu.synth.make_weights(cfg, seed=9, scale=0.05)
+    om = oracle.OracleModel(cfg, w)
+    shards = [gpu.HipTransformerModel(cfg, w, precision=precision, max_seqs=2, max_batch_tokens=256, tp_rank=r, tp_size=tp)
+              for r in range(tp)]
+    gpu.HipTransformerModel.attach_local_group(shards)
+    r = np.random.default_rng(2)
+    prompt = r.integers(0, cfg["vocab_size"], 90).tolist()      # prefill kernels (M > 64)
+    kv = om.new_cache()
+    want = om.forward_with_cache(prompt, kv, 0)
+    got = run_group(shards, lambda m: m.forward_with_cache(prompt, seq_id=1, pos_offset=0))
+    for g in got:
+        assert rel_err(g, want) <= TOL[precision]
+        assert np.array_equal(g, got[0])                         # replicated logits: every rank identical
+    pos = len(prompt)
+    for t in r.integers(0, cfg["vocab_size"], 3).tolist():       # decode kernels (pending-residual norm path)
+        want = om.forward_with_cache([t], kv, pos)[-1]
+        got = run_group(shards, lambda m: m.forward_with_cache([t], seq_id=1, pos_offset=pos, all_logits=False)[-1])
+        for g in got:
+            assert rel_err(g, want) <= TOL[precision]
+            assert np.array_equal(g, got[0])
+        pos += 1
+    for m in shards:
+        m.close()
+
+
+def test_tp_rejects_what_it_cannot_shard(gpu):
+    cfg = gpu.synth.tiny_config("falcon")          # MQA: one KV head
+    with pytest.raises(gpu.NvlError) as e:
+        gpu.HipTransformerModel(cfg, None, tp_rank=0, tp_size=2)
+    assert e.value.code == -1
+    cfg = gpu.synth.tiny_config("llama")           # 4 q / 2 kv heads do not divide by 4
+    with pytest.raises(gpu.NvlError):
+        gpu.HipTransformerModel(cfg, None, tp_rank=0, tp_size=4)
+    m = gpu.HipTransformerModel(cfg, gpu.synth.make_weights(cfg), tp_rank=1, tp_size=2, max_batch_tokens=64)
+    m.seq_reset(1)
+    with pytest.raises(gpu.NvlError):              # no communicator attached
+        m.forward_batch([1], [[1, 2, 3]], [0])
+    m.close()
+
+
+def test_rccl_single_rank_communicator(gpu):
+    """The RCCL code path with the one GPU this box has: a 1-rank communicator (all-reduce of one buffer)."""
+    cfg = gpu.synth.tiny_config("llama")
+    w = gpu.synth.make_weights(cfg, seed=9, scale=0.05)
+    uid = gpu.HipTransformerModel.tp_unique_id()
+    assert len(uid) == 128
+    ref = gpu.HipTransformerModel(cfg, w, precision="bf16", max_seqs=2, max_batch_tokens=256)
+    one = gpu.HipTransformerModel(cfg, w, precision="bf16", max_seqs=2, max_batch_tokens=256, tp_force_single=True)
+    one.tp_init(uid)                                   # ncclCommInitRank(nranks = 1)
+    toks = np.random.default_rng(3).integers(0, cfg["vocab_size"], 70).tolist()
+    a = ref.forward_with_cache(toks, 1, 0)
+    b = one.forward_with_cache(toks, 1, 0)             # O / W2 go through partial + ncclAllReduce + residual add
+    assert rel_err(b, a) <= 1e-5
+    a = ref.forward_with_cache([5], 1, 70, all_logits=False)
+    b = one.forward_with_cache([5], 1, 70, all_logits=False)
+    assert rel_err(b, a) <= 1e-5
+    ref.close()
+    one.close()
