@@ -668,7 +668,11 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
     const int U = MT <= 2 ? 4 : 2;                       // register budget: (1+MT)*U*2 fragments
     const int nblocks = cdiv(cdiv(a.N, 16), NTW);        // weight rows are padded to 128: all tiles exist
     const int KS = (EPI == EPI_RESID && a.sk_part && a.sk_slices > 1) ? a.sk_slices : 1;
-    int ksplit = g_force_ksplit ? g_force_ksplit : 16;
+    // waves per launch: enough to cover HBM latency on every CU (~2-4 thousand), not more — extra K slices only
+    // shorten each wave's stream below the depth of its two-block pipeline (r01 sweeps: LM head, W1)
+    int ksplit = 16;
+    if (g_force_ksplit) ksplit = g_force_ksplit;
+    else while (ksplit > 1 && (int64_t)nblocks * KS * NTW * ksplit > 4096) ksplit >>= 1;
     while (ksplit > 1 && ((a.K >> 5) / (ksplit * KS) < U || ksplit * NTW > 16)) ksplit >>= 1;   // >= one block of U k-steps per wave
     if (a.K % 32 != 0) return false;
     const size_t lds = (size_t)NTW * ksplit * MT * 64 * 16;
