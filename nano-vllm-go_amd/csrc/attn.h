@@ -37,6 +37,13 @@ struct AttnArgs {
     const int32_t* seq_slot;
     int nH, nKV, group;
     float scale;
+    // fused decode (attn_decode_bf16_kernel<.., FUSED>): q/k/v of the NEW token come straight from the fp32 output of
+    // the QKV projection ([tokens][qkv_stride] = [Q heads | K heads | V heads]); RoPE (rope.go:153-205) is applied here
+    // and the new K/V row is appended to the slabs by this kernel (replaces rope_kv_kernel + the q round trip)
+    const float* qkv;
+    int qkv_stride;
+    const float* cos_t;   // [max_seq][HD] or NULL
+    const float* sin_t;
 };
 
 template <int HD>
@@ -182,9 +189,28 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
 // and no barrier in the loop), and the NW partial results are merged once through LDS
 // (flash-decoding combine, fixed wave order).  Same transposed MFMA dataflow as the prefill kernel.
 // ------------------------------------------------------------------------------------------
-template <int HD, int NW>
+// rotate one (lo, hi) pair of 8-wide chunks: lo = d0..d0+7 (< HD/2), hi = the same offsets + HD/2
+__device__ __forceinline__ void rope_pair8(const float* row, const float* cs, const float* sn, int d0, int half,
+                                           bf16x8& lo, bf16x8& hi) {
+    const f32x4 a0 = *(const f32x4*)(row + d0), a1 = *(const f32x4*)(row + d0 + 4);
+    const f32x4 b0 = *(const f32x4*)(row + d0 + half), b1 = *(const f32x4*)(row + d0 + half + 4);
+    f32x4 yl0 = a0, yl1 = a1, yh0 = b0, yh1 = b1;
+    if (cs) {
+        const f32x4 c0 = *(const f32x4*)(cs + d0), c1 = *(const f32x4*)(cs + d0 + 4);
+        const f32x4 s0 = *(const f32x4*)(sn + d0), s1 = *(const f32x4*)(sn + d0 + 4);
+        yl0 = a0 * c0 + (-b0) * s0; yl1 = a1 * c1 + (-b1) * s1;     // x*cos + rotate_half(x)*sin (table halves duplicate)
+        yh0 = b0 * c0 + a0 * s0;    yh1 = b1 * c1 + a1 * s1;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        lo[e] = (bf16_t)yl0[e]; lo[4 + e] = (bf16_t)yl1[e];
+        hi[e] = (bf16_t)yh0[e]; hi[4 + e] = (bf16_t)yh1[e];
+    }
+}
+
+template <int HD, int NW, bool FUSED>
 __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
-    constexpr int KS = HD / 32, DT = HD / 16;
+    constexpr int KS = HD / 32, DT = HD / 16, HALF = HD / 2;
     __shared__ float red_m[NW][16];
     __shared__ float red_l[NW][16];
     __shared__ f32x4 red_o[NW][DT][64];
@@ -194,13 +220,41 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
     const int fq = lane & 15, fg = lane >> 4;
     const bool row_ok = fq < p.group;
     const int head = kvh * p.group + (row_ok ? fq : 0);
-    const bf16_t* qp = (const bf16_t*)p.q + (int64_t)tok * p.q_stride + head * HD;
     bf16x8 qf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) qf[ks] = *(const bf16x8*)(qp + ks * 32 + fg * 8);
     const int n_kt = pos0 / 64 + 1;
     const bf16_t* kbase = (const bf16_t*)p.kcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
     const bf16_t* vbase = (const bf16_t*)p.vcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
+    // FUSED: the new token's K row (RoPE applied) as this lane's operand chunks, and its V values for this lane's d
+    bf16x8 knew[KS];
+    bf16_t vnew[DT];
+    if (FUSED) {
+        const float* row = p.qkv + (int64_t)tok * p.qkv_stride;
+        const float* cs = p.cos_t ? p.cos_t + (int64_t)pos0 * HD : nullptr;
+        const float* sn = p.sin_t ? p.sin_t + (int64_t)pos0 * HD : nullptr;
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ks++) {
+            rope_pair8(row + head * HD, cs, sn, ks * 32 + fg * 8, HALF, qf[ks], qf[ks + KS / 2]);
+            rope_pair8(row + (p.nH + kvh) * HD, cs, sn, ks * 32 + fg * 8, HALF, knew[ks], knew[ks + KS / 2]);
+        }
+        const float* vrow = row + (p.nH + p.nKV + kvh) * HD;
+#pragma unroll
+        for (int d = 0; d < DT; d++) vnew[d] = (bf16_t)vrow[d * 16 + fq];
+        // append to the slabs for the following steps (this step uses the register copies: no read-after-write here)
+        if (wave == 0 && fq == 0) {      // lanes fg = 0..3 of column 0 hold all of K_new between them
+            bf16_t* kd = (bf16_t*)p.kcache + (int64_t)slot * p.slot_stride + ((int64_t)kvh * p.Tmax + pos0) * HD;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) *(bf16x8*)(kd + ks * 32 + fg * 8) = knew[ks];
+        }
+        if (wave == 1 % NW && fg == 0) {  // lanes fq = 0..15 hold V_new[16d + fq]
+            bf16_t* vd = (bf16_t*)p.vcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD + pos0;
+#pragma unroll
+            for (int d = 0; d < DT; d++) vd[(int64_t)(d * 16 + fq) * p.Tmax] = vnew[d];
+        }
+    } else {
+        const bf16_t* qp = (const bf16_t*)p.q + (int64_t)tok * p.q_stride + head * HD;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) qf[ks] = *(const bf16x8*)(qp + ks * 32 + fg * 8);
+    }
 
     f32x4 o[DT];
 #pragma unroll
@@ -223,6 +277,26 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
                 vlo[u][d] = *(const bf16x4*)(vr);
                 vhi[u][d] = *(const bf16x4*)(vr + 16);
             }
+        if (FUSED && kt == n_kt - 1) {
+            // the tile that holds key pos0: its slab row is not written yet (or not visible): patch the operands
+            const int kl = pos0 & 63;
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                if (t == (kl >> 4) && fq == (kl & 15)) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ks++) kf[t][ks] = knew[ks];
+                }
+            const int r32 = kl & 31, hi_half = r32 >> 4, fg0 = (r32 & 15) >> 2, j0 = r32 & 3;
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int d = 0; d < DT; d++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (u == (kl >> 5) && fg == fg0 && j == j0) {
+                            if (hi_half) vhi[u][d][j] = vnew[d]; else vlo[u][d][j] = vnew[d];
+                        }
+        }
         f32x4 s[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) {

@@ -762,7 +762,7 @@ void norm(nvl_model* m, float* x, const int32_t* rows_idx, const DevTensor& w, c
     NVL_HIP(hipGetLastError());
 }
 
-void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, double flops) {
+void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, double flops, bool fused_qkv = false) {
     AttnArgs a{};
     a.q = m->q; a.q_stride = m->nH * m->hd;
     a.out = m->attn_out; a.out_stride = m->nH * m->hd;
@@ -777,8 +777,14 @@ void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, do
         hipLaunchKernelGGL(attn_f32_kernel, dim3(max_len, m->nH, n_seqs), dim3(256), lds, m->stream, a, m->hd);
     } else if (max_len == 1 && m->group <= 16) {
         dim3 grid(m->nKV, n_seqs);
-        if (m->hd == 64) hipLaunchKernelGGL((attn_decode_bf16_kernel<64, 8>), grid, dim3(512), 0, m->stream, a);
-        else hipLaunchKernelGGL((attn_decode_bf16_kernel<128, 8>), grid, dim3(512), 0, m->stream, a);
+        if (fused_qkv) {   // RoPE + KV append + attention in one launch, straight from the QKV projection's fp32 output
+            a.qkv = m->qkv; a.qkv_stride = m->n_qkv; a.cos_t = m->rope_cos; a.sin_t = m->rope_sin;
+            if (m->hd == 64) hipLaunchKernelGGL((attn_decode_bf16_kernel<64, 8, true>), grid, dim3(512), 0, m->stream, a);
+            else hipLaunchKernelGGL((attn_decode_bf16_kernel<128, 8, true>), grid, dim3(512), 0, m->stream, a);
+        } else {
+            if (m->hd == 64) hipLaunchKernelGGL((attn_decode_bf16_kernel<64, 8, false>), grid, dim3(512), 0, m->stream, a);
+            else hipLaunchKernelGGL((attn_decode_bf16_kernel<128, 8, false>), grid, dim3(512), 0, m->stream, a);
+        }
     } else {
         const int qtiles = cdiv((int64_t)max_len * m->group, 64);
         dim3 grid(qtiles, m->nKV, n_seqs);
@@ -1058,6 +1064,7 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
     for (int li = 0; li < m->L; li++) {
         const LayerW& l = m->layers[li];
         norm(m, m->x, nullptr, l.t[NVL_T_ATTN_NORM_W], l.t[NVL_T_ATTN_NORM_B], m->xn, M);
+        bool fused_dec = false;
         if (!m->f32 && m->hd == 64 && M > 64) {
             // prefill: RoPE + Q/K/V placement fused into the projection's epilogue (no fp32 qkv round trip)
             GemmArgs a = mk(m->xn, H, l.w_qkv, nullptr, 0, l.b_qkv, 1.f, M, m->n_qkv, H);
@@ -1069,9 +1076,10 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
             gemm(m, EPI_QKV, false, a);
         } else {
             gemm(m, EPI_STORE, true, mk(m->xn, H, l.w_qkv, m->qkv, m->n_qkv, l.b_qkv, 1.f, M, m->n_qkv, H));
-            rope_kv(m, li, md, M);
+            fused_dec = !m->f32 && max_len == 1 && m->group <= 16;     // decode: RoPE + KV append live in the attention kernel
+            if (!fused_dec) rope_kv(m, li, md, M);
         }
-        attention(m, li, md, n_seqs, max_len, attn_flops);
+        attention(m, li, md, n_seqs, max_len, attn_flops, fused_dec);
         const float* bo = (const float*)l.t[NVL_T_BO].p;
         if (parallel) {
             // generic_model.go:395-418: r + [am*]attn + [rm*]ffn, both branches read the same normed x
