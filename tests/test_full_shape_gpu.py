@@ -1,0 +1,80 @@
+"""Parity at the BASELINE configs' FULL layer shapes, where the tiny fixtures cannot reach:
+Falcon's H = 4544 = 71 x 64 (not a multiple of 128), MQA with 71 query heads on one KV head, Llama's 128256-row
+tied LM head, GPT-2's odd vocabulary, Granite's 32-expert top-8 routing.  Layer COUNT is reduced (the layers are
+identical in shape) so the CPU oracle finishes in seconds; widths, head counts, vocabularies and expert counts
+are the real ones.  Plus size-independent properties on the device path alone: batch invariance, chunked
+prefill == one-shot prefill, incremental decode == re-prefill."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1.5e-2     # bf16 product path, relative to max |logit|
+
+CASES = {
+    # name: (full config key, layers kept)
+    "gpt2": ("gpt2", 3),
+    "llama-3.2-1b": ("llama-3.2-1b", 2),
+    "falcon-7b": ("falcon-7b", 1),
+    "granite-3.0-1b-a400m": ("granite-3.0-1b-a400m", 2),
+    "llama-3-8b": ("llama-3-8b", 1),            # head_dim 128, GQA 32/8, F 14336 (config 5's shapes, one GPU)
+}
+
+
+def make(gpu, name, seed=21):
+    key, layers = CASES[name]
+    cfg = dict(gpu.synth.FULL_CONFIGS[key], num_layers=layers)
+    w = gpu.synth.make_weights(cfg, seed=seed, scale=0.02)
+    return cfg, w
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_full_width_layers_match_oracle(gpu, oracle, name):
+    cfg, w = make(gpu, name)
+    om = oracle.OracleModel(cfg, w)
+    hm = gpu.HipTransformerModel(cfg, w, precision="bf16", max_seqs=4, max_batch_tokens=512)
+    r = np.random.default_rng(5)
+    prompt = r.integers(0, cfg["vocab_size"], 5).tolist()
+    kv = om.new_cache()
+    want = om.forward_with_cache(prompt, kv, 0)[-1]
+    got = hm.forward_with_cache(prompt, seq_id=1, pos_offset=0, all_logits=False)[-1]
+    assert rel_err(got, want) <= TOL
+    tok = oracle.argmax(want)
+    want = om.forward_with_cache([tok], kv, 5)[-1]
+    got = hm.forward_with_cache([tok], seq_id=1, pos_offset=5, all_logits=False)[-1]
+    assert rel_err(got, want) <= TOL
+    hm.close()
+
+
+@pytest.mark.parametrize("name", ["llama-3.2-1b", "falcon-7b", "granite-3.0-1b-a400m"])
+def test_device_path_properties_at_full_width(gpu, name):
+    """No oracle: properties that must hold at any size."""
+    cfg, w = make(gpu, name)
+    hm = gpu.HipTransformerModel(cfg, w, precision="bf16", max_seqs=8, max_batch_tokens=1024)
+    r = np.random.default_rng(6)
+    V = cfg["vocab_size"]
+    a = r.integers(0, V, 200).tolist()
+    others = [r.integers(0, V, n).tolist() for n in (77, 130, 3)]
+    # (1) batch invariance: a's last-row logits do not depend on its batch mates (prefill tile kernels, ragged batch)
+    for i in range(4):
+        hm.seq_reset(i)
+    solo, _ = hm.forward_batch([0], [a], [0])
+    for i in range(4):
+        hm.seq_reset(i)
+    mixed, _ = hm.forward_batch([1, 0, 2, 3], [others[0], a, others[1], others[2]], [0, 0, 0, 0])
+    assert rel_err(mixed[1], solo[0]) <= 2e-3        # same arithmetic; only tile membership differs
+    # (2) chunked prefill (cache + new block) == one-shot prefill
+    hm.seq_reset(5)
+    hm.forward_batch([5], [a[:120]], [0], want_logits=False)
+    chunked, _ = hm.forward_batch([5], [a[120:]], [120])
+    assert rel_err(chunked[0], solo[0]) <= TOL
+    # (3) incremental decode == prefill of the extended history (decode kernels vs prefill kernels)
+    nxt = int(np.argmax(solo[0]))
+    hm.seq_reset(0)
+    hm.forward_batch([0], [a], [0], want_logits=False)
+    dec, _ = hm.forward_batch([0], [[nxt]], [200])
+    hm.seq_reset(6)
+    ref, _ = hm.forward_batch([6], [a + [nxt]], [0])
+    assert rel_err(dec[0], ref[0]) <= TOL
+    hm.close()
