@@ -44,7 +44,7 @@ struct QkvEpi {             // EPI_QKV only
     bf16_t* kcache;         // layer base
     bf16_t* vcache;
     int64_t slot_stride;
-    int Tmax, nH, nKV;
+    int Tmax, nH, nKV, hd;
 };
 
 struct GemmArgs {
@@ -134,43 +134,34 @@ __device__ __forceinline__ void epilogue_swiglu4(const GemmArgs& p, int m, int f
     act_store4<OutT>((OutT*)p.C, (int64_t)p.c_row0 + m, f, p.ldc, v);
 }
 
-// EPI_QKV: one wave sub-tile of 64 columns = one head (hd 64).  The lane holds, for token m,
-// d = 16j + 4fg + r (j = 0..3): the RoPE partner d+32 is tile j+2 of the SAME lane.
-__device__ __forceinline__ void epilogue_qkv_head(const GemmArgs& p, int m, int head, int fg, f32x4 (&t)[4]) {
+// EPI_QKV: one wave sub-tile of TH*16 columns = one head (TH = 4: hd 64, TH = 8: hd 128).  The lane holds, for
+// token m, d = 16j + 4fg + r (j = 0..TH-1): the RoPE partner d + hd/2 is tile j + TH/2 of the SAME lane.
+template <int TH>
+__device__ __forceinline__ void epilogue_qkv_head(const GemmArgs& p, int m, int head, int fg, f32x4 (&t)[TH]) {
+    constexpr int HD = TH * 16;
     if (m >= p.M) return;
     const QkvEpi& q = p.qkv;
     if (p.bias) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const f32x4 b = *(const f32x4*)(p.bias + head * 64 + 16 * j + 4 * fg);
-            t[j] += b;
-        }
+        for (int j = 0; j < TH; j++) t[j] += *(const f32x4*)(p.bias + head * HD + 16 * j + 4 * fg);
     }
     const int pos = q.tok_pos[m];
     if (head < q.nH + q.nKV && q.cos_t) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const f32x4 c = *(const f32x4*)(q.cos_t + (int64_t)pos * 64 + 16 * j + 4 * fg);
-            const f32x4 s = *(const f32x4*)(q.sin_t + (int64_t)pos * 64 + 16 * j + 4 * fg);
-            const f32x4 x1 = t[j], x2 = t[j + 2];
-            t[j] = x1 * c + (-x2) * s;          // rope.go:196-202 (table halves are duplicates: cos[d+32] == cos[d])
-            t[j + 2] = x2 * c + x1 * s;
+        for (int j = 0; j < TH / 2; j++) {
+            const f32x4 c = *(const f32x4*)(q.cos_t + (int64_t)pos * HD + 16 * j + 4 * fg);
+            const f32x4 s = *(const f32x4*)(q.sin_t + (int64_t)pos * HD + 16 * j + 4 * fg);
+            const f32x4 x1 = t[j], x2 = t[j + TH / 2];
+            t[j] = x1 * c + (-x2) * s;          // rope.go:196-202 (table halves are duplicates: cos[d+hd/2] == cos[d])
+            t[j + TH / 2] = x2 * c + x1 * s;
         }
     }
-    if (head < q.nH) {
-        bf16_t* dst = q.q_out + (int64_t)m * (q.nH * 64) + head * 64 + 4 * fg;
+    if (head < q.nH + q.nKV) {
+        bf16_t* dst = head < q.nH
+            ? q.q_out + (int64_t)m * (q.nH * HD) + head * HD + 4 * fg
+            : q.kcache + (int64_t)q.tok_slot[m] * q.slot_stride + ((int64_t)(head - q.nH) * q.Tmax + pos) * HD + 4 * fg;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            bf16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; r++) o[r] = (bf16_t)t[j][r];
-            *(bf16x4*)(dst + 16 * j) = o;
-        }
-    } else if (head < q.nH + q.nKV) {
-        const int kvh = head - q.nH;
-        bf16_t* dst = q.kcache + (int64_t)q.tok_slot[m] * q.slot_stride + ((int64_t)kvh * q.Tmax + pos) * 64 + 4 * fg;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < TH; j++) {
             bf16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; r++) o[r] = (bf16_t)t[j][r];
@@ -178,9 +169,9 @@ __device__ __forceinline__ void epilogue_qkv_head(const GemmArgs& p, int m, int 
         }
     } else {
         const int kvh = head - q.nH - q.nKV;
-        bf16_t* dst = q.vcache + (int64_t)q.tok_slot[m] * q.slot_stride + (int64_t)kvh * q.Tmax * 64 + pos;
+        bf16_t* dst = q.vcache + (int64_t)q.tok_slot[m] * q.slot_stride + (int64_t)kvh * q.Tmax * HD + pos;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < TH; j++)
 #pragma unroll
             for (int r = 0; r < 4; r++) dst[(int64_t)(16 * j + 4 * fg + r) * q.Tmax] = (bf16_t)t[j][r];
     }
@@ -346,9 +337,9 @@ void gemm_bf16_kernel(GemmArgs p) {
     for (int i = 0; i < TM; i++) {
         const int m = m0 + wm * (TM * 16) + i * 16 + fr;
         if (EPI == EPI_QKV) {
-            static_assert(TN == 4, "EPI_QKV needs a 64-column wave tile (one head)");
-            const int head = (n0 + wn * 64) >> 6;
-            if (head * 64 < p.N) epilogue_qkv_head(p, m, head, fg, acc[i]);
+            // the wave's column tile is exactly one head: TN = 4 <-> head_dim 64, TN = 8 <-> head_dim 128
+            const int head = (n0 + wn * (TN * 16)) / (TN * 16);
+            if (head * (TN * 16) < p.N) epilogue_qkv_head<TN>(p, m, head, fg, acc[i]);
         } else if (EPI == EPI_SWIGLU) {
 #pragma unroll
             for (int j = 0; j < TN; j += 2) {
@@ -465,7 +456,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pipe_kernel(GemmArgs p) {
         const int m = m0 + wm * (TM * 16) + i * 16 + fr;
         if (EPI == EPI_QKV) {
             const int head = (n0 + wn * 64) >> 6;
-            if (head * 64 < p.N) epilogue_qkv_head(p, m, head, fg, acc[i]);
+            if (head * 64 < p.N) epilogue_qkv_head<4>(p, m, head, fg, acc[i]);
         } else if (EPI == EPI_SWIGLU) {
 #pragma unroll
             for (int j = 0; j < TN; j += 2) {
@@ -729,6 +720,12 @@ template <int EPI, typename OutT>
 static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
     if (a.tile_map) { launch_gemm_grouped<EPI, OutT>(st, a, a.M); return; }   // a.M carries the m-tile bound
     if (launch_gemm_skinny_bf16<EPI, OutT>(st, a)) return;
+    if constexpr (EPI == EPI_QKV) {
+        if (a.qkv.hd == 128) {     // a wave must own a whole 128-column head: 256x256 tile as 4x2 waves of 64x128
+            launch_gemm_tile<256, 256, 4, 2, 2, EPI, OutT>(st, a);
+            return;
+        }
+    }
     int tile = g_force_tile;
     if (tile == 0) {
         tile = 1;

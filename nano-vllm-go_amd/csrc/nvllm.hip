@@ -1065,14 +1065,14 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
         const LayerW& l = m->layers[li];
         norm(m, m->x, nullptr, l.t[NVL_T_ATTN_NORM_W], l.t[NVL_T_ATTN_NORM_B], m->xn, M);
         bool fused_dec = false;
-        if (!m->f32 && m->hd == 64 && M > 64) {
+        if (!m->f32 && M > 64) {
             // prefill: RoPE + Q/K/V placement fused into the projection's epilogue (no fp32 qkv round trip)
             GemmArgs a = mk(m->xn, H, l.w_qkv, nullptr, 0, l.b_qkv, 1.f, M, m->n_qkv, H);
             a.qkv.tok_pos = md.tok_pos; a.qkv.tok_slot = md.tok_slot; a.qkv.cos_t = m->rope_cos; a.qkv.sin_t = m->rope_sin;
             a.qkv.q_out = (bf16_t*)m->q;
             a.qkv.kcache = (bf16_t*)m->kcache + (int64_t)li * m->layer_stride;
             a.qkv.vcache = (bf16_t*)m->vcache + (int64_t)li * m->layer_stride;
-            a.qkv.slot_stride = m->slot_stride; a.qkv.Tmax = m->Tmax; a.qkv.nH = m->nH; a.qkv.nKV = m->nKV;
+            a.qkv.slot_stride = m->slot_stride; a.qkv.Tmax = m->Tmax; a.qkv.nH = m->nH; a.qkv.nKV = m->nKV; a.qkv.hd = m->hd;
             gemm(m, EPI_QKV, false, a);
         } else {
             gemm(m, EPI_STORE, true, mk(m->xn, H, l.w_qkv, m->qkv, m->n_qkv, l.b_qkv, 1.f, M, m->n_qkv, H));

@@ -47,7 +47,7 @@ def test_full_width_layers_match_oracle(gpu, oracle, name):
     hm.close()
 
 
-@pytest.mark.parametrize("name", ["llama-3.2-1b", "falcon-7b", "granite-3.0-1b-a400m"])
+@pytest.mark.parametrize("name", ["llama-3.2-1b", "falcon-7b", "granite-3.0-1b-a400m", "llama-3-8b"])
 def test_device_path_properties_at_full_width(gpu, name):
     """No oracle: properties that must hold at any size."""
     cfg, w = make(gpu, name)

@@ -165,3 +165,31 @@ def test_errors_instead_of_panics(gpu, oracle):
         hm.forward_batch([1], [[1]], [5])
     assert e.value.code == -1
     hm.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("ntok", [29, 150])
+def test_head_dim_128(gpu, oracle, precision, ntok):
+    """Llama-3-8B's head geometry (head_dim 128, GQA) on a small model: prefill (fused QKV epilogue on the 4x2-wave
+    256x256 instance), decode (fused RoPE + attention), KV contents."""
+    cfg = gpu.synth.tiny_config("llama", head_dim=128, hidden=256, num_heads=4, num_kv_heads=2, ffn_dim=512)
+    w = gpu.synth.make_weights(cfg, seed=13, scale=0.05)
+    om = oracle.OracleModel(cfg, w)
+    hm = gpu.HipTransformerModel(cfg, w, precision=precision, max_seqs=2, max_batch_tokens=256)
+    r = np.random.default_rng(8)
+    toks = r.integers(0, cfg["vocab_size"], ntok).tolist()
+    kv = om.new_cache()
+    want = om.forward_with_cache(toks, kv, 0)
+    got = hm.forward_with_cache(toks, seq_id=1, pos_offset=0)
+    assert rel_err(got, want) <= TOL[precision]
+    for li in range(cfg["num_layers"]):
+        k_ref, v_ref = kv.layer(li, 2, 128)
+        k_dev, v_dev = hm.get_kv(1, li)
+        assert rel_err(k_dev, k_ref) <= TOL[precision] and rel_err(v_dev, v_ref) <= TOL[precision]
+    pos = ntok
+    for t in r.integers(0, cfg["vocab_size"], 3).tolist():
+        want = om.forward_with_cache([t], kv, pos)[-1]
+        got = hm.forward_with_cache([t], seq_id=1, pos_offset=pos, all_logits=False)[-1]
+        assert rel_err(got, want) <= TOL[precision]
+        pos += 1
+    hm.close()
