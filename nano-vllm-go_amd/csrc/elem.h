@@ -469,18 +469,6 @@ __global__ void convert_1d_kernel(const void* __restrict__ src, int dtype, float
     if (i < n) dst[i] = ld_as_f32(src, dtype, src_off + i);
 }
 
-// Decode weight prefetch: touch a weight range with plain (allocating) loads so it sits in the 256 MiB Infinity
-// Cache when the projection that streams it starts.  Runs on a side stream beside latency-bound kernels
-// (attention, norms); reads only, the XOR keeps the loads alive, the store never executes.
-__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__ p, int64_t n16, uint32_t* __restrict__ sink) {
-    uint32_t acc = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint4 v = p[i];
-        acc ^= v.x ^ v.y ^ v.z ^ v.w;
-    }
-    if (acc == 0x9e3779b9u && threadIdx.x == 1023) *sink = acc;
-}
-
 // tensor parallel: x[m][:] += alpha * (part[m][:] (+ bias))  after the all-reduce of a row-parallel projection
 __global__ void axpy_rows_kernel(float* __restrict__ x, const float* __restrict__ part, const float* __restrict__ bias,
                                  float alpha, int64_t rows, int H) {

@@ -53,7 +53,6 @@ struct nvl_model {
     bool finalized = false;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t pf_stream = nullptr;     // side stream: decode weight prefetch (read-only, no ordering needed)
     std::string err;
 
     // derived (nH, nKV, F are the LOCAL sizes of this tensor-parallel rank; *_full the model's)

@@ -176,7 +176,6 @@ extern "C" int nvl_create(const nvl_model_config* cfg, const nvl_runtime_opts* o
     m->device = opts->device;
     NVL_HIP(hipSetDevice(m->device));
     NVL_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-    NVL_HIP(hipStreamCreateWithFlags(&m->pf_stream, hipStreamNonBlocking));
     NVL_HIP(hipEventCreate(&m->ev0));
     NVL_HIP(hipEventCreate(&m->ev1));
     m->H = c.hidden; m->nH = c.num_heads; m->hd = c.head_dim; m->F = c.ffn_dim; m->V = c.vocab_size;
@@ -239,7 +238,6 @@ extern "C" void nvl_destroy(nvl_model* m) {
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
-    if (m->pf_stream) { (void)hipStreamSynchronize(m->pf_stream); (void)hipStreamDestroy(m->pf_stream); }
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -863,12 +861,6 @@ void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
     }
 }
 
-static int g_prefetch = 1;     // tuning key 2: decode weight prefetch on the side stream (0 off)
-void prefetch_weights(nvl_model* m, const void* p, int64_t bytes) {
-    if (!p || bytes <= 0) return;
-    hipLaunchKernelGGL(prefetch_kernel, dim3(128), dim3(256), 0, m->pf_stream, (const uint4*)p, bytes / 16, (uint32_t*)m->argmax_dev);
-}
-
 // Residual projection (O projection / W2): x += alpha * (A·W^T + bias)   (generic_model.go:320-326,383-389).
 // Prefill and the fp32 mode fuse the add into the GEMM epilogue.  Decode-sized batches split K over
 // `slices` workgroups per column block so that all 256 CUs stream weights (a 2048-column projection has
@@ -1071,16 +1063,6 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
 
     for (int li = 0; li < m->L; li++) {
         const LayerW& l = m->layers[li];
-        if (g_prefetch && !m->f32 && M <= 64 && !c.use_moe) {
-            // decode: while this layer's latency-bound kernels run, pull its FFN weights (and the next layer's
-            // attention weights) toward the Infinity Cache on the side stream
-            prefetch_weights(m, l.w1, (int64_t)l.n1 * H * 2);
-            prefetch_weights(m, l.t[NVL_T_W2].p, (int64_t)H * m->F * 2);
-            if (li + 1 < m->L) {
-                prefetch_weights(m, m->layers[li + 1].w_qkv, (int64_t)m->n_qkv * H * 2);
-                prefetch_weights(m, m->layers[li + 1].t[NVL_T_WO].p, (int64_t)H * m->nH * m->hd * 2);
-            }
-        }
         norm(m, m->x, nullptr, l.t[NVL_T_ATTN_NORM_W], l.t[NVL_T_ATTN_NORM_B], m->xn, M);
         bool fused_dec = false;
         if (!m->f32 && M > 64) {
