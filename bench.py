@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="sequences per GPU")
     ap.add_argument("--prompt", type=int, default=512, help="prompt tokens per sequence")
     ap.add_argument("--gen", type=int, default=128, help="decode steps per sequence")
+    ap.add_argument("--decode", choices=["fused", "stepwise"], default="fused",
+                    help="fused: the G greedy steps in one nvl_decode_greedy call (token feedback on the device); "
+                         "stepwise: one nvl_forward per step with the token round trip through the host")
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-prompt", type=int, default=8)
@@ -196,9 +199,12 @@ def main():
             nxt[b0:b0 + len(ids)] = am
         model.set_profile(False)
         t_b = time.perf_counter()
-        for g in range(G):
-            _, am = model.forward_batch(seq_ids, [[int(t)] for t in nxt], [S + g] * B, want_logits=False)
-            nxt = am
+        if args.decode == "fused":
+            model.decode_greedy(seq_ids, nxt, G)
+        else:
+            for g in range(G):
+                _, am = model.forward_batch(seq_ids, [[int(t)] for t in nxt], [S + g] * B, want_logits=False)
+                nxt = am
         t_c = time.perf_counter()
         return t_b - t_a, t_c - t_b
 
@@ -256,7 +262,7 @@ def main():
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong" if tp else "weak",
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic (seeded random weights at the model's "
         "shapes, uniform random token ids)",
-        "config": {"workload": f"{args.model}: {B} seqs/GPU x {S} prompt tokens prefill + {G} greedy decode steps",
+        "config": {"workload": f"{args.model}: {B} seqs/GPU x {S} prompt tokens prefill + {G} greedy decode steps ({args.decode})",
                    "batch_per_gpu": B, "prompt_len": S, "gen_len": G, "parallelism": (f"tp{world} (column/row-parallel, RCCL all-reduce)" if tp else f"dp{world} over sequences")},
         "prefill_tokens_per_s": round(nrep * B * S * args.steps / pre_s, 1),
         "decode_tokens_per_s": round(nrep * B * G * args.steps / dec_s, 1),

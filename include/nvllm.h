@@ -177,6 +177,13 @@ int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t*
                 const int32_t* seq_lens, const int32_t* pos_offsets, uint32_t flags,
                 float* logits_out, int32_t* argmax_out);
 
+/* The greedy generation loop of cmd/ask (generateResponse, cmd/ask/main.go:315-360, without its EOS/"User" stop: the
+ * caller truncates) for a batch, as ONE call: n_steps decode steps of one token per sequence starting from
+ * first_tokens (the tokens sampled from the prefill), each step's device argmax fed back without a host round trip.
+ * out_tokens receives [n_steps][n_seqs].  Same arithmetic, bit for bit, as n_steps calls of nvl_forward. */
+int nvl_decode_greedy(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* first_tokens, int n_steps,
+                      int32_t* out_tokens);
+
 /* Debug/parity: copy the residual stream after layer `layer` of the LAST nvl_forward call,
  * [sum(seq_lens), H] fp32 (requires nvl_set_debug(m, 1) before the call). */
 int nvl_set_debug(nvl_model* m, int keep_hidden);

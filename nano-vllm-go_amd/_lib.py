@@ -99,6 +99,7 @@ def lib():
         getattr(L, fn).argtypes = [vp, i64]
     L.nvl_seq_close_all.argtypes = [vp]
     L.nvl_forward.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_uint32, vp, vp]
+    L.nvl_decode_greedy.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
     L.nvl_set_debug.argtypes = [vp, C.c_int]
     L.nvl_get_hidden.argtypes = [vp, C.c_int, vp, i64]
     L.nvl_get_kv.argtypes = [vp, i64, C.c_int, vp, vp]

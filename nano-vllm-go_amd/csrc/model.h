@@ -100,6 +100,7 @@ struct nvl_model {
     float* sk_part = nullptr; int sk_max_slices = 4; int pending_slices = 0, pending_rows = 0; float pending_alpha = 1.f; const float* pending_part = nullptr;
     // per-call metadata (one pinned host block mirrored on the device)
     int32_t* meta_host = nullptr; int32_t* meta_dev = nullptr; int64_t meta_ints = 0;
+    int32_t* ring = nullptr; int64_t ring_ints = 0;   // nvl_decode_greedy: [steps][seqs] tokens on the device
     // debug
     bool keep_hidden = false; float* hidden = nullptr; int64_t hidden_tokens = 0; int hidden_last_M = 0;
     // stats

@@ -227,7 +227,7 @@ extern "C" void nvl_destroy(nvl_model* m) {
     dfree(m->x); dfree(m->xn); dfree(m->qkv); dfree(m->q); dfree(m->attn_out); dfree(m->hbuf); dfree(m->h2);
     dfree(m->xn_last); dfree(m->logits); dfree(m->argmax_dev); dfree(m->argmax_pval); dfree(m->argmax_pidx); dfree(m->router_logits); dfree(m->expert_ids);
     dfree(m->expert_w); dfree(m->seg_start); dfree(m->moe_counts); dfree(m->moe_cursor); dfree(m->moe_tile_map); dfree(m->moe_n_mtiles); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo);
-    dfree(m->meta_dev); dfree(m->hidden); dfree(m->sk_part); dfree(m->tp_part);
+    dfree(m->meta_dev); dfree(m->hidden); dfree(m->sk_part); dfree(m->tp_part); dfree(m->ring);
     if (m->tp_comm) (void)ncclCommDestroy((ncclComm_t)m->tp_comm);
     if (m->tp_local) {
         bool last;
@@ -980,57 +980,13 @@ void moe(nvl_model* m, const LayerW& l, int M) {
 
 }  // namespace
 
-extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* tokens,
-                           const int32_t* seq_lens, const int32_t* pos_offsets, uint32_t flags,
-                           float* logits_out, int32_t* argmax_out) {
-    if (!m) return NVL_ERR_INVALID;
-    if (!m->finalized) return fail(m, NVL_ERR_STATE, "nvl_forward: model not finalized");
-    if (n_seqs <= 0 || !seq_ids || !tokens || !seq_lens || !pos_offsets)
-        return fail(m, NVL_ERR_INVALID, "nvl_forward: null/empty arguments");
-    if (n_seqs > m->opts.max_seqs) return fail(m, NVL_ERR_INVALID, "nvl_forward: n_seqs exceeds max_seqs");
-    NVL_TRY(m)
-    NVL_HIP(hipSetDevice(m->device));
+namespace {
+// Enqueue ONE forward pass (embedding ... argmax) on the model's stream for the batch described by the device
+// metadata `md` — no host synchronisation.  Returns the number of logits rows produced.
+int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len, double attn_flops, uint32_t flags) {
     const nvl_model_config& c = m->cfg;
     const int H = m->H;
-    // ---- validate + build metadata -------------------------------------------------------
-    int64_t M64 = 0; int max_len = 0; bool prefill = false;
-    for (int i = 0; i < n_seqs; i++) {
-        if (seq_lens[i] <= 0) return fail(m, NVL_ERR_INVALID, "nvl_forward: empty sequence");
-        M64 += seq_lens[i]; max_len = std::max(max_len, seq_lens[i]);
-        if (seq_lens[i] > 1) prefill = true;
-    }
-    if (M64 > m->opts.max_batch_tokens) return fail(m, NVL_ERR_INVALID, "nvl_forward: batch exceeds max_batch_tokens");
-    const int M = (int)M64;
-    int32_t* h = m->meta_host;
-    const int64_t Mmax = m->opts.max_batch_tokens, S = m->opts.max_seqs;
-    (void)Mmax;
-    int32_t *h_sts = h, *h_len = h_sts + S, *h_pos = h_len + S, *h_slot = h_pos + S, *h_last = h_slot + S,
-            *h_tokens = h + 5 * S, *h_tok_pos = h_tokens + M, *h_tok_slot = h_tok_pos + M;
-    int t = 0;
-    for (int i = 0; i < n_seqs; i++) {
-        auto it = m->seq_slot.find(seq_ids[i]);
-        if (it == m->seq_slot.end()) return fail(m, NVL_ERR_UNKNOWN_SEQ, "nvl_forward: sequence has no KV slot (nvl_seq_open first)");
-        const int slot = it->second;
-        for (int j = 0; j < i; j++) if (seq_ids[j] == seq_ids[i]) return fail(m, NVL_ERR_INVALID, "nvl_forward: duplicate sequence in batch");
-        if (pos_offsets[i] != m->slot_len[(size_t)slot]) return fail(m, NVL_ERR_INVALID, "nvl_forward: pos_offset does not equal the cached length");
-        if (pos_offsets[i] + seq_lens[i] > c.max_seq_len)   // rope.go:84-86 / :176-178 panic
-            return fail(m, NVL_ERR_POSITION, "nvl_forward: position exceeds max_seq_len");
-        h_sts[i] = t; h_len[i] = seq_lens[i]; h_pos[i] = pos_offsets[i]; h_slot[i] = slot;
-        for (int j = 0; j < seq_lens[i]; j++, t++) {
-            const int tok = tokens[t];
-            if (tok < 0 || tok >= m->V) return fail(m, NVL_ERR_INVALID, "nvl_forward: token id out of range");
-            h_tokens[t] = tok; h_tok_pos[t] = pos_offsets[i] + j; h_tok_slot[t] = slot;
-        }
-        h_last[i] = t - 1;
-    }
-    Meta md;
-    md.seq_tok_start = m->meta_dev; md.seq_len = md.seq_tok_start + S; md.seq_pos = md.seq_len + S;
-    md.seq_slot = md.seq_pos + S; md.last_rows = md.seq_slot + S;
-    md.tokens = m->meta_dev + 5 * S; md.tok_pos = md.tokens + M; md.tok_slot = md.tok_pos + M;
-    NVL_HIP(hipEventRecord(m->ev0, m->stream));
     m->pending_slices = 0;
-    NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, (size_t)(5 * S + 3 * (int64_t)M) * 4, hipMemcpyHostToDevice, m->stream));
-
     if (m->keep_hidden && m->hidden_tokens < M) {
         dfree(m->hidden);
         m->hidden = dmalloc<float>((int64_t)m->L * M * H);
@@ -1052,12 +1008,6 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
         NVL_HIP(hipGetLastError());
     }
 
-    // attention FLOPs of this call (4*hd per (query, visible key) pair per head)
-    double attn_flops = 0;
-    for (int i = 0; i < n_seqs; i++) {
-        const double s = seq_lens[i], p0 = pos_offsets[i];
-        attn_flops += 4.0 * m->hd * m->nH * (s * p0 + s * (s + 1) / 2);
-    }
     const int qw = m->nH * m->hd;
     const bool parallel = c.block_style == NVL_BLOCK_PARALLEL;
 
@@ -1121,6 +1071,81 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
                       m->argmax_dev);
         NVL_HIP(hipGetLastError());
     }
+    return rows;
+}
+
+// after a decode step: feed the greedy tokens back as the next step's inputs and advance every position by one
+// (cmd/ask/main.go:315-320: allTokens = append(allTokens, nextToken); ForwardWithCache([last], kv, len-1))
+__global__ void advance_decode_kernel(const int32_t* __restrict__ argmax, int32_t* __restrict__ tokens,
+                                      int32_t* __restrict__ tok_pos, int32_t* __restrict__ seq_pos,
+                                      int32_t* __restrict__ out_step, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = argmax[i];
+    out_step[i] = t;
+    tokens[i] = t;
+    tok_pos[i] += 1;
+    seq_pos[i] += 1;
+}
+}  // namespace
+
+extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* tokens,
+                           const int32_t* seq_lens, const int32_t* pos_offsets, uint32_t flags,
+                           float* logits_out, int32_t* argmax_out) {
+    if (!m) return NVL_ERR_INVALID;
+    if (!m->finalized) return fail(m, NVL_ERR_STATE, "nvl_forward: model not finalized");
+    if (n_seqs <= 0 || !seq_ids || !tokens || !seq_lens || !pos_offsets)
+        return fail(m, NVL_ERR_INVALID, "nvl_forward: null/empty arguments");
+    if (n_seqs > m->opts.max_seqs) return fail(m, NVL_ERR_INVALID, "nvl_forward: n_seqs exceeds max_seqs");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    const nvl_model_config& c = m->cfg;
+    const int H = m->H;
+    // ---- validate + build metadata -------------------------------------------------------
+    int64_t M64 = 0; int max_len = 0; bool prefill = false;
+    for (int i = 0; i < n_seqs; i++) {
+        if (seq_lens[i] <= 0) return fail(m, NVL_ERR_INVALID, "nvl_forward: empty sequence");
+        M64 += seq_lens[i]; max_len = std::max(max_len, seq_lens[i]);
+        if (seq_lens[i] > 1) prefill = true;
+    }
+    if (M64 > m->opts.max_batch_tokens) return fail(m, NVL_ERR_INVALID, "nvl_forward: batch exceeds max_batch_tokens");
+    const int M = (int)M64;
+    int32_t* h = m->meta_host;
+    const int64_t Mmax = m->opts.max_batch_tokens, S = m->opts.max_seqs;
+    (void)Mmax;
+    int32_t *h_sts = h, *h_len = h_sts + S, *h_pos = h_len + S, *h_slot = h_pos + S, *h_last = h_slot + S,
+            *h_tokens = h + 5 * S, *h_tok_pos = h_tokens + M, *h_tok_slot = h_tok_pos + M;
+    int t = 0;
+    for (int i = 0; i < n_seqs; i++) {
+        auto it = m->seq_slot.find(seq_ids[i]);
+        if (it == m->seq_slot.end()) return fail(m, NVL_ERR_UNKNOWN_SEQ, "nvl_forward: sequence has no KV slot (nvl_seq_open first)");
+        const int slot = it->second;
+        for (int j = 0; j < i; j++) if (seq_ids[j] == seq_ids[i]) return fail(m, NVL_ERR_INVALID, "nvl_forward: duplicate sequence in batch");
+        if (pos_offsets[i] != m->slot_len[(size_t)slot]) return fail(m, NVL_ERR_INVALID, "nvl_forward: pos_offset does not equal the cached length");
+        if (pos_offsets[i] + seq_lens[i] > c.max_seq_len)   // rope.go:84-86 / :176-178 panic
+            return fail(m, NVL_ERR_POSITION, "nvl_forward: position exceeds max_seq_len");
+        h_sts[i] = t; h_len[i] = seq_lens[i]; h_pos[i] = pos_offsets[i]; h_slot[i] = slot;
+        for (int j = 0; j < seq_lens[i]; j++, t++) {
+            const int tok = tokens[t];
+            if (tok < 0 || tok >= m->V) return fail(m, NVL_ERR_INVALID, "nvl_forward: token id out of range");
+            h_tokens[t] = tok; h_tok_pos[t] = pos_offsets[i] + j; h_tok_slot[t] = slot;
+        }
+        h_last[i] = t - 1;
+    }
+    Meta md;
+    md.seq_tok_start = m->meta_dev; md.seq_len = md.seq_tok_start + S; md.seq_pos = md.seq_len + S;
+    md.seq_slot = md.seq_pos + S; md.last_rows = md.seq_slot + S;
+    md.tokens = m->meta_dev + 5 * S; md.tok_pos = md.tokens + M; md.tok_slot = md.tok_pos + M;
+    NVL_HIP(hipEventRecord(m->ev0, m->stream));
+    NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, (size_t)(5 * S + 3 * (int64_t)M) * 4, hipMemcpyHostToDevice, m->stream));
+
+    double attn_flops = 0;   // 4*hd per (query, visible key) pair per head
+    for (int i = 0; i < n_seqs; i++) {
+        const double s = seq_lens[i], p0 = pos_offsets[i];
+        attn_flops += 4.0 * m->hd * m->nH * (s * p0 + s * (s + 1) / 2);
+    }
+    const bool all = (flags & NVL_FWD_ALL_LOGITS) != 0;
+    const int rows = enqueue_forward(m, md, n_seqs, M, max_len, attn_flops, flags);
     NVL_HIP(hipEventRecord(m->ev1, m->stream));
     std::vector<int32_t> am((size_t)rows);
     NVL_HIP(hipMemcpyAsync(am.data(), m->argmax_dev, (size_t)rows * 4, hipMemcpyDeviceToHost, m->stream));
@@ -1138,6 +1163,69 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
     m->stats.forward_calls++;
     if (prefill) { m->stats.prefill_tokens += (uint64_t)M; m->stats.prefill_ms += ms; }
     else { m->stats.decode_tokens += (uint64_t)M; m->stats.decode_ms += ms; }
+    if (m->profile) drain_profile(m);
+    return NVL_OK;
+    NVL_CATCH(m)
+}
+
+// The greedy decode loop of cmd/ask (main.go:315-360, without the EOS stop) as ONE call: `n_steps` forward passes of one
+// token per sequence, each step's argmax fed back on the device — no host round trip between steps.  Identical
+// arithmetic to calling nvl_forward n_steps times with the returned tokens.
+extern "C" int nvl_decode_greedy(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* first_tokens,
+                                 int n_steps, int32_t* out_tokens) {
+    if (!m) return NVL_ERR_INVALID;
+    if (!m->finalized) return fail(m, NVL_ERR_STATE, "nvl_decode_greedy: model not finalized");
+    if (n_seqs <= 0 || n_steps <= 0 || !seq_ids || !first_tokens || !out_tokens)
+        return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy: null/empty arguments");
+    if (n_seqs > m->opts.max_seqs || n_seqs > m->opts.max_batch_tokens)
+        return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy: n_seqs exceeds max_seqs / max_batch_tokens");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    const int64_t S = m->opts.max_seqs;
+    const int M = n_seqs;
+    int32_t* h = m->meta_host;
+    int32_t *h_sts = h, *h_len = h_sts + S, *h_pos = h_len + S, *h_slot = h_pos + S, *h_last = h_slot + S,
+            *h_tokens = h + 5 * S, *h_tok_pos = h_tokens + M, *h_tok_slot = h_tok_pos + M;
+    for (int i = 0; i < n_seqs; i++) {
+        auto it = m->seq_slot.find(seq_ids[i]);
+        if (it == m->seq_slot.end()) return fail(m, NVL_ERR_UNKNOWN_SEQ, "nvl_decode_greedy: sequence has no KV slot");
+        for (int j = 0; j < i; j++) if (seq_ids[j] == seq_ids[i]) return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy: duplicate sequence");
+        const int slot = it->second, pos = m->slot_len[(size_t)slot];
+        if (pos + n_steps > m->cfg.max_seq_len) return fail(m, NVL_ERR_POSITION, "nvl_decode_greedy: position exceeds max_seq_len");
+        if (first_tokens[i] < 0 || first_tokens[i] >= m->V) return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy: token id out of range");
+        h_sts[i] = i; h_len[i] = 1; h_pos[i] = pos; h_slot[i] = slot; h_last[i] = i;
+        h_tokens[i] = first_tokens[i]; h_tok_pos[i] = pos; h_tok_slot[i] = slot;
+    }
+    Meta md;
+    md.seq_tok_start = m->meta_dev; md.seq_len = md.seq_tok_start + S; md.seq_pos = md.seq_len + S;
+    md.seq_slot = md.seq_pos + S; md.last_rows = md.seq_slot + S;
+    md.tokens = m->meta_dev + 5 * S; md.tok_pos = md.tokens + M; md.tok_slot = md.tok_pos + M;
+    if ((int64_t)n_steps * n_seqs > m->ring_ints) {
+        dfree(m->ring);
+        m->ring_ints = (int64_t)n_steps * n_seqs;
+        m->ring = dmalloc<int32_t>(m->ring_ints);
+    }
+    NVL_HIP(hipEventRecord(m->ev0, m->stream));
+    NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, (size_t)(5 * S + 3 * (int64_t)M) * 4, hipMemcpyHostToDevice, m->stream));
+    const bool dbg = m->keep_hidden;
+    m->keep_hidden = false;                      // the per-layer taps belong to single nvl_forward calls
+    for (int s = 0; s < n_steps; s++) {
+        double attn_flops = 0;
+        for (int i = 0; i < n_seqs; i++) attn_flops += 4.0 * m->hd * m->nH * (double)(h_pos[i] + s + 1);
+        enqueue_forward(m, md, n_seqs, M, 1, attn_flops, 0);
+        hipLaunchKernelGGL(advance_decode_kernel, dim3(cdiv(n_seqs, 256)), dim3(256), 0, m->stream, m->argmax_dev, md.tokens,
+                           md.tok_pos, md.seq_pos, m->ring + (int64_t)s * n_seqs, n_seqs);
+        NVL_HIP(hipGetLastError());
+    }
+    m->keep_hidden = dbg;
+    NVL_HIP(hipEventRecord(m->ev1, m->stream));
+    NVL_HIP(hipMemcpyAsync(out_tokens, m->ring, (size_t)n_steps * n_seqs * 4, hipMemcpyDeviceToHost, m->stream));
+    NVL_HIP(hipStreamSynchronize(m->stream));
+    for (int i = 0; i < n_seqs; i++) m->slot_len[(size_t)h_slot[i]] += n_steps;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, m->ev0, m->ev1);
+    m->stats.forward_calls += (uint64_t)n_steps;
+    m->stats.decode_tokens += (uint64_t)n_steps * n_seqs; m->stats.decode_ms += ms;
     if (m->profile) drain_profile(m);
     return NVL_OK;
     NVL_CATCH(m)

@@ -145,6 +145,24 @@ class HipTransformerModel:
             all_tokens.append(out[-1])
         return out
 
+    def decode_greedy(self, seq_ids, first_tokens, n_steps: int):
+        """nvl_decode_greedy: n_steps greedy decode steps with the token feedback on the device -> [n_steps, n_seqs]."""
+        n = len(seq_ids)
+        ids = np.ascontiguousarray(seq_ids, dtype=np.int64)
+        first = np.ascontiguousarray(first_tokens, dtype=np.int32)
+        out = np.empty((n_steps, n), dtype=np.int32)
+        L.check(self.lib.nvl_decode_greedy(self.h, n, _ptr(ids), _ptr(first), n_steps, _ptr(out)), self.h)
+        return out
+
+    def greedy_fused(self, prompt, max_tokens: int, seq_id: int = 0):
+        """greedy() with the whole decode loop in one nvl_decode_greedy call."""
+        self.seq_reset(seq_id)
+        _, am = self.forward_batch([seq_id], [list(prompt)], [0], want_logits=False)
+        out = [int(am[0])]
+        if max_tokens > 1:
+            out += [int(t) for t in self.decode_greedy([seq_id], [out[0]], max_tokens - 1)[:, 0]]
+        return out
+
     # -- debug / parity taps ------------------------------------------------------------------------
     def set_debug(self, keep_hidden: bool):
         L.check(self.lib.nvl_set_debug(self.h, int(keep_hidden)), self.h)

@@ -193,3 +193,37 @@ def test_head_dim_128(gpu, oracle, precision, ntok):
         assert rel_err(got, want) <= TOL[precision]
         pos += 1
     hm.close()
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_decode_greedy_equals_stepwise(gpu, oracle, family, precision):
+    """nvl_decode_greedy (token feedback on the device) == the same loop driven step by step through nvl_forward
+    (cmd/ask/main.go:315-360), bit for bit, for a ragged batch; the cached lengths advance the same way."""
+    cfg, om, hm = build(gpu, oracle, family, precision)
+    r = np.random.default_rng(11)
+    prompts = [r.integers(0, cfg["vocab_size"], n).tolist() for n in (9, 33, 2)]
+    steps = 12
+    ids = [0, 1, 2]
+    for i in ids:
+        hm.seq_reset(i)
+    _, first = hm.forward_batch(ids, prompts, [0, 0, 0], want_logits=False)
+    want, cur, pos = [], first.copy(), [len(p) for p in prompts]
+    for s in range(steps):
+        _, cur = hm.forward_batch(ids, [[int(t)] for t in cur], [p + s for p in pos], want_logits=False)
+        want.append(cur.copy())
+    for i in ids:
+        hm.seq_reset(i)
+    _, first2 = hm.forward_batch(ids, prompts, [0, 0, 0], want_logits=False)
+    assert (first2 == first).all()
+    got = hm.decode_greedy(ids, first2, steps)
+    assert (got == np.stack(want)).all()
+    assert [hm.seq_len(i) for i in ids] == [p + steps for p in pos]
+    # the call after it continues from the advanced cache
+    _, nxt = hm.forward_batch(ids, [[int(t)] for t in got[-1]], [p + steps for p in pos], want_logits=False)
+    assert nxt.shape == (3,)
+    # errors: running past max_seq_len is refused up front, nothing is advanced
+    with pytest.raises(Exception):
+        hm.decode_greedy(ids, got[-1], cfg["max_seq_len"])
+    assert [hm.seq_len(i) for i in ids] == [p + steps + 1 for p in pos]
+    hm.close()
