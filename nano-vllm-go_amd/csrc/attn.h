@@ -239,17 +239,6 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
         const float* vrow = row + (p.nH + p.nKV + kvh) * HD;
 #pragma unroll
         for (int d = 0; d < DT; d++) vnew[d] = (bf16_t)vrow[d * 16 + fq];
-        // append to the slabs for the following steps (this step uses the register copies: no read-after-write here)
-        if (wave == 0 && fq == 0) {      // lanes fg = 0..3 of column 0 hold all of K_new between them
-            bf16_t* kd = (bf16_t*)p.kcache + (int64_t)slot * p.slot_stride + ((int64_t)kvh * p.Tmax + pos0) * HD;
-#pragma unroll
-            for (int ks = 0; ks < KS; ks++) *(bf16x8*)(kd + ks * 32 + fg * 8) = knew[ks];
-        }
-        if (wave == 1 % NW && fg == 0) {  // lanes fq = 0..15 hold V_new[16d + fq]
-            bf16_t* vd = (bf16_t*)p.vcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD + pos0;
-#pragma unroll
-            for (int d = 0; d < DT; d++) vd[(int64_t)(d * 16 + fq) * p.Tmax] = vnew[d];
-        }
     } else {
         const bf16_t* qp = (const bf16_t*)p.q + (int64_t)tok * p.q_stride + head * HD;
 #pragma unroll
@@ -261,89 +250,116 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
     for (int d = 0; d < DT; d++) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
-    for (int kt = wave; kt < n_kt; kt += NW) {
-        bf16x8 kf[4][KS];
-        bf16x4 vlo[2][DT], vhi[2][DT];
+    // Each wave owns key tiles wave, wave+NW, ...; the loads of TWO of its tiles are issued before either is used
+    // (a decode step is latency-bound: ~150 KB per workgroup), so sequences up to 2*NW*64 keys take one round trip.
+    constexpr int NT2 = HD <= 64 ? 2 : 1;      // hd 128: one tile's operands already fill the register budget
+    bf16x8 kf[NT2][4][KS];
+    bf16x4 vlo[NT2][2][DT], vhi[NT2][2][DT];
+    for (int kt0 = wave; kt0 < n_kt; kt0 += NT2 * NW) {
 #pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int ks = 0; ks < KS; ks++)
-                kf[t][ks] = *(const bf16x8*)(kbase + (int64_t)(kt * 64 + t * 16 + fq) * HD + ks * 32 + fg * 8);
-#pragma unroll
-        for (int u = 0; u < 2; u++)
-#pragma unroll
-            for (int d = 0; d < DT; d++) {
-                const bf16_t* vr = vbase + (int64_t)(d * 16 + fq) * p.Tmax + kt * 64 + u * 32 + fg * 4;
-                vlo[u][d] = *(const bf16x4*)(vr);
-                vhi[u][d] = *(const bf16x4*)(vr + 16);
-            }
-        if (FUSED && kt == n_kt - 1) {
-            // the tile that holds key pos0: its slab row is not written yet (or not visible): patch the operands
-            const int kl = pos0 & 63;
+        for (int h = 0; h < NT2; h++) {
+            const int kt = kt0 + h * NW;
+            if (kt >= n_kt) continue;
 #pragma unroll
             for (int t = 0; t < 4; t++)
-                if (t == (kl >> 4) && fq == (kl & 15)) {
 #pragma unroll
-                    for (int ks = 0; ks < KS; ks++) kf[t][ks] = knew[ks];
-                }
-            const int r32 = kl & 31, hi_half = r32 >> 4, fg0 = (r32 & 15) >> 2, j0 = r32 & 3;
+                for (int ks = 0; ks < KS; ks++)
+                    kf[h][t][ks] = *(const bf16x8*)(kbase + (int64_t)(kt * 64 + t * 16 + fq) * HD + ks * 32 + fg * 8);
 #pragma unroll
             for (int u = 0; u < 2; u++)
 #pragma unroll
-                for (int d = 0; d < DT; d++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if (u == (kl >> 5) && fg == fg0 && j == j0) {
-                            if (hi_half) vhi[u][d][j] = vnew[d]; else vlo[u][d][j] = vnew[d];
-                        }
+                for (int d = 0; d < DT; d++) {
+                    const bf16_t* vr = vbase + (int64_t)(d * 16 + fq) * p.Tmax + kt * 64 + u * 32 + fg * 4;
+                    vlo[h][u][d] = *(const bf16x4*)(vr);
+                    vhi[h][u][d] = *(const bf16x4*)(vr + 16);
+                }
         }
-        f32x4 s[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < NT2; h++) {
+            const int kt = kt0 + h * NW;
+            if (kt >= n_kt) continue;
+            if (FUSED && kt == n_kt - 1) {
+                // the tile that holds key pos0: its slab row is not written yet (or not visible): patch the operands
+                const int kl = pos0 & 63;
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][ks], qf[ks], s[t], 0, 0, 0);
+                for (int t = 0; t < 4; t++)
+                    if (t == (kl >> 4) && fq == (kl & 15)) {
+#pragma unroll
+                        for (int ks = 0; ks < KS; ks++) kf[h][t][ks] = knew[ks];
+                    }
+                const int r32 = kl & 31, hi_half = r32 >> 4, fg0 = (r32 & 15) >> 2, j0 = r32 & 3;
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int d = 0; d < DT; d++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (u == (kl >> 5) && fg == fg0 && j == j0) {
+                                if (hi_half) vhi[h][u][d][j] = vnew[d]; else vlo[h][u][d][j] = vnew[d];
+                            }
+            }
+            f32x4 s[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[h][t][ks], qf[ks], s[t], 0, 0, 0);
+            }
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int key = kt * 64 + t * 16 + fg * 4 + r;
+                    float v = s[t][r] * p.scale;
+                    v = (key <= pos0) ? v : -INFINITY;
+                    s[t][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);     // finite: every tile kt < n_kt holds key kt*64 <= pos0
+            const float alpha = __expf(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float pv = __expf(s[t][r] - m_new);
+                    s[t][r] = pv;
+                    psum += pv;
+                }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int d = 0; d < DT; d++) o[d] *= alpha;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                bf16x8 pf;
+#pragma unroll
+                for (int r = 0; r < 4; r++) { pf[r] = (bf16_t)s[2 * u][r]; pf[4 + r] = (bf16_t)s[2 * u + 1][r]; }
+#pragma unroll
+                for (int d = 0; d < DT; d++) {
+                    bf16x8 vf;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { vf[r] = vlo[h][u][d][r]; vf[4 + r] = vhi[h][u][d][r]; }
+                    o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[d], 0, 0, 0);
+                }
+            }
         }
-        float tmax = -INFINITY;
+    }
+    if (FUSED) {
+        // append the new key/value to the slabs for the following steps — after every load of this step (which used
+        // the register copies), so the loads above are not ordered behind these stores
+        if (wave == 0 && fq == 0) {      // lanes fg = 0..3 of column 0 hold all of K_new between them
+            bf16_t* kd = (bf16_t*)p.kcache + (int64_t)slot * p.slot_stride + ((int64_t)kvh * p.Tmax + pos0) * HD;
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+            for (int ks = 0; ks < KS; ks++) *(bf16x8*)(kd + ks * 32 + fg * 8) = knew[ks];
+        }
+        if (wave == 1 % NW && fg == 0) {  // lanes fq = 0..15 hold V_new[16d + fq]
+            bf16_t* vd = (bf16_t*)p.vcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD + pos0;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int key = kt * 64 + t * 16 + fg * 4 + r;
-                float v = s[t][r] * p.scale;
-                v = (key <= pos0) ? v : -INFINITY;
-                s[t][r] = v;
-                tmax = fmaxf(tmax, v);
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);     // finite: every tile kt < n_kt holds key kt*64 <= pos0
-        const float alpha = __expf(m_run - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float pv = __expf(s[t][r] - m_new);
-                s[t][r] = pv;
-                psum += pv;
-            }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < DT; d++) o[d] *= alpha;
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            bf16x8 pf;
-#pragma unroll
-            for (int r = 0; r < 4; r++) { pf[r] = (bf16_t)s[2 * u][r]; pf[4 + r] = (bf16_t)s[2 * u + 1][r]; }
-#pragma unroll
-            for (int d = 0; d < DT; d++) {
-                bf16x8 vf;
-#pragma unroll
-                for (int r = 0; r < 4; r++) { vf[r] = vlo[u][d][r]; vf[4 + r] = vhi[u][d][r]; }
-                o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[d], 0, 0, 0);
-            }
+            for (int d = 0; d < DT; d++) vd[(int64_t)(d * 16 + fq) * p.Tmax] = vnew[d];
         }
     }
     l_run += __shfl_xor(l_run, 16, 64);

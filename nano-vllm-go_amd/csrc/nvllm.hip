@@ -887,7 +887,7 @@ void resid_gemm(nvl_model* m, const void* A, int lda, const void* W, const float
     if (!m->f32 && M <= 64 && !m->keep_hidden && m->sk_part && m->pending_slices == 0 && N % 16 == 0) {
         const int nblocks = N / 16;
         if (g_sk_slices > 0) slices = g_sk_slices;
-        else while (slices < m->sk_max_slices && nblocks * slices < 512 && (K >> 5) / (slices * 2) >= 8) slices *= 2;
+        else while (slices < m->sk_max_slices && nblocks * slices < 256 && (K >> 5) / (slices * 2) >= 8) slices *= 2;
     }
     if (slices > 1) {
         a.sk_part = m->sk_part; a.sk_slices = slices;
