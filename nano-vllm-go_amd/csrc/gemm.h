@@ -649,6 +649,102 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 // ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// bf16 skinny kernel, wide-N form (decode projections with >= 256 groups of 64 weight rows: FFN up, LM head).
+// A wave owns NTB 16-row weight tiles over its K slice, so every activation fragment it fetches from L2 feeds
+// NTB MFMAs instead of one: L2->CU traffic per weight byte drops from 1 + MT to 1 + MT/NTB (the activation
+// fetches were costing ~15 % of the streaming rate, r01 probe).  8 waves per workgroup (256-VGPR budget): two
+// register sets of U k-steps x (NTB weight + MT activation) fragments — for K = 2048 a wave's whole slice is in
+// flight at once.  Same deterministic in-LDS K reduction and fused epilogues as the narrow form.
+// ------------------------------------------------------------------------------------------
+template <int MT, int NTB, int U, int EPI, typename OutT>
+__global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* red = (f32x4*)smem;                       // [ksplit][NTB][MT][64]
+    const int tid = threadIdx.x, lane = tid & 63, kw = tid >> 6;
+    const int ksplit = blockDim.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nt0 = blockIdx.x * NTB;
+    const int nks = p.K >> 5, q = nks / ksplit, rr = nks - q * ksplit;
+    const int my_steps = q + (kw < rr ? 1 : 0);
+    const int ks0 = kw * q + (kw < rr ? kw : rr);
+    const int64_t tile_stride = (int64_t)nks * 512;  // elements between consecutive 16-row weight tiles
+
+    const bf16_t* wp = (const bf16_t*)p.W + (((int64_t)nt0 * nks + ks0) * 64 + lane) * 8;
+    const bf16_t* xp = (const bf16_t*)p.A + ((int64_t)ks0 * 64 + lane) * 8;
+    f32x4 acc[NTB][MT];
+#pragma unroll
+    for (int t = 0; t < NTB; t++)
+#pragma unroll
+        for (int i = 0; i < MT; i++) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nblk = my_steps / U;
+    bf16x8 wA[U][NTB], xA[U][MT], wB[U][NTB], xB[U][MT];
+    auto load_blk = [&](bf16x8 (&w)[U][NTB], bf16x8 (&x)[U][MT], int b) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int t = 0; t < NTB; t++)
+                w[u][t] = __builtin_nontemporal_load((const bf16x8*)(wp + t * tile_stride + (int64_t)(b * U + u) * 512));
+#pragma unroll
+            for (int i = 0; i < MT; i++) x[u][i] = *(const bf16x8*)(xp + i * tile_stride + (int64_t)(b * U + u) * 512);
+        }
+    };
+    auto comp_blk = [&](bf16x8 (&w)[U][NTB], bf16x8 (&x)[U][MT]) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int t = 0; t < NTB; t++)
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][t], x[u][i], acc[t][i], 0, 0, 0);
+    };
+    if (nblk > 0) load_blk(wA, xA, 0);
+    int b = 0;
+    for (; b + 2 <= nblk; b += 2) {
+        load_blk(wB, xB, b + 1);
+        comp_blk(wA, xA);
+        if (b + 2 < nblk) load_blk(wA, xA, b + 2);
+        comp_blk(wB, xB);
+    }
+    if (b < nblk) comp_blk(wA, xA);
+    for (int s = nblk * U; s < my_steps; s++) {      // ragged tail
+        bf16x8 xs[MT];
+#pragma unroll
+        for (int i = 0; i < MT; i++) xs[i] = *(const bf16x8*)(xp + i * tile_stride + (int64_t)s * 512);
+#pragma unroll
+        for (int t = 0; t < NTB; t++) {
+            const bf16x8 w = __builtin_nontemporal_load((const bf16x8*)(wp + t * tile_stride + (int64_t)s * 512));
+#pragma unroll
+            for (int i = 0; i < MT; i++) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xs[i], acc[t][i], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < NTB; t++)
+#pragma unroll
+        for (int i = 0; i < MT; i++) red[((kw * NTB + t) * MT + i) * 64 + lane] = acc[t][i];
+    __syncthreads();
+    auto ksum = [&](int t, int i) {
+        f32x4 s = red[(t * MT + i) * 64 + lane];
+        for (int w = 1; w < ksplit; w++) s += red[((w * NTB + t) * MT + i) * 64 + lane];
+        return s;
+    };
+    if (EPI == EPI_SWIGLU) {
+        // tiles come as [gate16 | up16] pairs of the same 16 features
+        for (int e = kw; e < (NTB / 2) * MT; e += ksplit) {
+            const int j = e / MT, i = e - j * MT;
+            const int f = ((nt0 >> 1) + j) * 16 + 4 * fg;
+            epilogue_swiglu4<OutT>(p, 16 * i + fr, f, ksum(2 * j, i), ksum(2 * j + 1, i));
+        }
+    } else {
+        for (int e = kw; e < NTB * MT; e += ksplit) {
+            const int t = e / MT, i = e - t * MT;
+            epilogue4<EPI, OutT>(p, 16 * i + fr, (nt0 + t) * 16 + 4 * fg, ksum(t, i));
+        }
+    }
+}
+
 static int g_force_ntw = 0, g_force_ksplit = 0;   // tuning overrides (nvl_bench_gemm only)
 static int g_force_tile = 0;                      // 0 automatic, 1: 128x128x2st, 2: 256x128x3st, 3: 256x256x2st
 
@@ -674,9 +770,43 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
     return true;
 }
 template <int EPI, typename OutT>
+static inline bool launch_gemm_skinny_wide(hipStream_t st, const GemmArgs& a) {
+    constexpr int NTB = 4;
+    if (a.K % 32 != 0 || a.sk_part) return false;
+    const int groups = cdiv(cdiv(a.N, 16), NTB);     // weight rows are padded to 256: every tile of a group exists
+    const int MT = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+    const int U = MT <= 2 ? 4 : 2;
+    // ~1024 waves per launch (one 256-VGPR wave per SIMD, each with up to 32 KiB of weights in flight) stream best:
+    // longer per-wave K slices beat more waves (r01 probe: FFN-up ksplit 4, LM head and the 8B FFN-up ksplit 2)
+    int ksplit = 8;
+    if (g_force_ksplit) ksplit = g_force_ksplit <= 8 ? g_force_ksplit : 8;
+    else while (ksplit > 2 && groups * ksplit > 1024) ksplit >>= 1;
+    while (ksplit > 1 && (a.K >> 5) / ksplit < U) ksplit >>= 1;
+    const size_t lds = (size_t)ksplit * NTB * MT * 64 * 16;
+#define NVL_SKW(MTv, Uv)                                                                                               \
+    do {                                                                                                               \
+        static bool attr = false;                                                                                      \
+        if (!attr) {                                                                                                   \
+            (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_bf16_kernel<MTv, NTB, Uv, EPI, OutT>,              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 8 * NTB * MTv * 64 * 16);            \
+            attr = true;                                                                                               \
+        }                                                                                                              \
+        hipLaunchKernelGGL((gemm_skinny_wide_bf16_kernel<MTv, NTB, Uv, EPI, OutT>), dim3(groups), dim3(ksplit * 64),   \
+                           lds, st, a);                                                                                \
+    } while (0)
+    if (MT == 1) NVL_SKW(1, 4); else if (MT == 2) NVL_SKW(2, 4); else NVL_SKW(4, 2);
+#undef NVL_SKW
+    return true;
+}
+template <int EPI, typename OutT>
 static inline bool launch_gemm_skinny_bf16(hipStream_t st, const GemmArgs& a) {
     if (EPI == EPI_QKV) return false;               // prefill-only epilogue (a decode workgroup owns 16 columns, not a head)
     if (a.M > 64 || a.a_rows || a.seg || a.tile_map) return false;
+    if constexpr (EPI == EPI_SWIGLU || EPI == EPI_STORE || EPI == EPI_GELU) {
+        // wide-N form once its 64-row groups fill the chip (g_force_ntw: 8 forces it, 1/2/4 force the narrow form)
+        const bool wide_ok = a.M > 16 && cdiv(a.N, 64) >= 256 && !a.sk_part;   // M <= 16: the narrow form streams as fast
+        if (g_force_ntw == 8 || (g_force_ntw == 0 && wide_ok)) { if (launch_gemm_skinny_wide<EPI, OutT>(st, a)) return true; }
+    }
     if (EPI == EPI_SWIGLU) return launch_gemm_skinny_ntw<2, EPI, OutT>(st, a);
     if (g_force_ntw == 2) return launch_gemm_skinny_ntw<2, EPI, OutT>(st, a);
     if (g_force_ntw == 4) return launch_gemm_skinny_ntw<4, EPI, OutT>(st, a);

@@ -180,3 +180,39 @@ def test_argmax_first_max_tie_rule(gpu, oracle):
     x[2, :] = -1.0                  # all equal -> index 0
     got = gpu.ops.argmax(x)
     assert list(got) == [oracle.argmax(x[i]) for i in range(3)] == [5, 50256, 0]
+
+
+@pytest.mark.parametrize("form", [0, 1, 8])       # automatic, narrow (one weight tile per wave), wide-N (4 tiles per wave)
+@pytest.mark.parametrize("m,k,n", [(1, 256, 16400), (16, 192, 16384), (17, 512, 16448), (32, 2048, 16384),
+                                   (33, 320, 20000), (64, 1024, 16640)])
+def test_matmul_decode_forms(gpu, oracle, form, m, k, n):
+    """The two decode GEMM forms (gemm_skinny_bf16_kernel / gemm_skinny_wide_bf16_kernel) on ragged M, K (k-steps that
+    do not divide over the waves) and N (a last 64-row group that is partly padding)."""
+    r = rng(m * 7 + n)
+    a = r.standard_normal((m, k), dtype=np.float32)
+    b = r.standard_normal((k, n), dtype=np.float32) * 0.05
+    old = gpu.lib().nvl_set_tuning(2, form)
+    try:
+        got = gpu.ops.mat_mul(a, b, precision="bf16")
+        ai = np.zeros((m, k), np.float32)
+        ai[np.arange(min(m, k)), (np.arange(min(m, k)) * 5) % k] = 1.0      # rows pick distinct k: exact in bf16
+        bi = ((np.arange(k * n, dtype=np.int64).reshape(k, n) * 7) % 251).astype(np.float32)
+        goti = gpu.ops.mat_mul(ai, bi, precision="bf16")
+    finally:
+        gpu.lib().nvl_set_tuning(2, old)
+    assert rel_err(got, oracle.matmul(a, b)) <= BF16_TOL
+    assert np.array_equal(goti, oracle.matmul(ai, bi))
+
+
+@pytest.mark.parametrize("swiglu", [True, False])
+def test_ffn_wide_decode_form(gpu, oracle, swiglu):
+    """SwiGLU / GELU epilogues of the wide-N decode form (F large enough that its 64-row groups fill the chip)."""
+    r = rng(11)
+    rows, H, F = 20, 64, 8192 if swiglu else 16384
+    x = r.standard_normal((rows, H), dtype=np.float32)
+    w1 = r.standard_normal((H, 2 * F if swiglu else F), dtype=np.float32) * 0.1
+    w2 = r.standard_normal((F, H), dtype=np.float32) * 0.02
+    b1 = None if swiglu else r.standard_normal(F, dtype=np.float32) * 0.1
+    b2 = None if swiglu else r.standard_normal(H, dtype=np.float32) * 0.1
+    want = oracle.ffn(x, w1, b1, w2, b2, swiglu)
+    assert rel_err(gpu.ops.feed_forward(x, w1, b1, w2, b2, swiglu, precision="bf16"), want) <= BF16_TOL
