@@ -204,6 +204,30 @@ int nvl_runner_run(nvl_model* m, int n_seqs, const int64_t* seq_ids,
                    const int32_t* const* token_ptrs, const int32_t* token_lens,
                    int is_prefill, int32_t* next_tokens, float* logits_out);
 
+/* ---- sampling on the device (tensor.SampleWithHistory, purego/tensor/sampling.go:33-102) ---- */
+/* tensor.SamplingParams (sampling.go:10-15).  Reference quirks kept: temperature <= 0 or == 1 leaves the logits
+ * unscaled (:71; there is no greedy branch), top_k <= 0 or >= V is "off" (:78), top_p >= 1 is "off" (:83), the
+ * repetition penalty is multiplied by the token's count, the last 10 history tokens counting 3 (:46-66). */
+typedef struct nvl_sampling_params {
+    float   temperature;
+    float   top_p;
+    int32_t top_k;
+    float   repetition_penalty;
+} nvl_sampling_params;
+/* Sample one id per logits row of the LAST nvl_forward / nvl_runner_run group (rows in that call's sequence order), on
+ * the device: only ids cross PCIe.  history_ptrs[i]/history_lens[i] is the row's previousTokens (may be NULL/0);
+ * uniforms[i] replaces the rand.Float32() draw of sampleMultinomial (sampling.go:205), so the Go host keeps its
+ * math/rand stream: call rand.Float32() once per sequence, in order, and pass the values.  Sums run in a fixed tree
+ * order instead of the reference's sequential one: the id can differ from the Go result only when r lies within
+ * float rounding of a CDF step (tests/test_sampling_gpu.py states the bound). */
+int nvl_sample(nvl_model* m, int n_rows, const nvl_sampling_params* params, const int32_t* const* history_ptrs,
+               const int32_t* history_lens, const float* uniforms, int32_t* out_tokens);
+/* TensorModelRunner.Run including its sampling step (tensor_model_runner.go:55-97): nvl_runner_run, then
+ * SampleWithHistory(lastTokenLogits, seq.TokenIDs, defaultSampling) per sequence on the device. */
+int nvl_runner_run_sampled(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* const* token_ptrs,
+                           const int32_t* token_lens, int is_prefill, const nvl_sampling_params* params,
+                           const float* uniforms, int32_t* next_tokens);
+
 /* ---- measurement (the reference only has wall-clock prints: cmd/ask/main.go:196-198) ---- */
 typedef struct nvl_stats {
     uint64_t forward_calls, prefill_tokens, decode_tokens;
@@ -258,6 +282,10 @@ int nvl_op_moe(int device, int precision, const float* x, const float* router, c
 /* argmax cmd/ask/main.go:389-402 (first strict maximum) */
 int nvl_op_argmax(int device, const float* x, int rows, int cols, int32_t* out);
 
+/* sampling.go:33-102 on host logits [rows, V]; probs_out (optional) receives the final renormalised distribution. */
+int nvl_op_sample(int device, const float* logits, int rows, int V, const nvl_sampling_params* params,
+                  const int32_t* const* history_ptrs, const int32_t* history_lens, const float* uniforms,
+                  int32_t* out_tokens, float* probs_out);
 /* ---- tuning / measurement (no reference counterpart) ----
  * Times one projection GEMM shape (random bf16 operands resident in HBM) with HIP events on the
  * library's stream: avg_us per launch over `iters` back-to-back launches.  epi: 0 store-fp32,

@@ -69,6 +69,16 @@ class StatsC(C.Structure):
                 ("other_ms", C.c_double), ("other_launches", C.c_uint64), ("weight_bytes", C.c_double)]
 
 
+class SamplingParamsC(C.Structure):     # nvl_sampling_params == tensor.SamplingParams (sampling.go:10-15)
+    _fields_ = [("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_int32),
+                ("repetition_penalty", C.c_float)]
+
+
+def sampling_params(temperature=1.0, top_p=1.0, top_k=0, repetition_penalty=1.2) -> SamplingParamsC:
+    """DefaultSamplingParams (sampling.go:18-25) unless overridden."""
+    return SamplingParamsC(float(temperature), float(top_p), int(top_k), float(repetition_penalty))
+
+
 def declared_symbols() -> list[str]:
     """Every function include/nvllm.h declares (the drop-in surface)."""
     text = HEADER.read_text()
@@ -104,6 +114,9 @@ def lib():
     L.nvl_get_hidden.argtypes = [vp, C.c_int, vp, i64]
     L.nvl_get_kv.argtypes = [vp, i64, C.c_int, vp, vp]
     L.nvl_runner_run.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp]
+    L.nvl_sample.argtypes = [vp, C.c_int, C.POINTER(SamplingParamsC), vp, vp, vp, vp]
+    L.nvl_runner_run_sampled.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(SamplingParamsC), vp, vp]
+    L.nvl_op_sample.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.POINTER(SamplingParamsC), vp, vp, vp, vp, vp]
     L.nvl_set_profile.argtypes = [vp, C.c_int]
     L.nvl_get_stats.argtypes = [vp, C.POINTER(StatsC)]
     L.nvl_reset_stats.argtypes = [vp]

@@ -11,6 +11,7 @@
 #include "attn.h"
 #include "common.h"
 #include "elem.h"
+#include "sample.h"
 #include "gemm.h"
 
 namespace nvl {
@@ -36,6 +37,14 @@ struct ProfRec { hipEvent_t a, b; int cls; double flops; };
 }  // namespace nvl
 
 // in-process tensor-parallel group (tests on one GPU): see tp_allreduce in nvllm.hip
+// device scratch of the sampler (sample.h); grows on demand
+struct SampleBufs {
+    float* work = nullptr; int32_t* cnt = nullptr; int64_t elems = 0;     // [rows][V] each; cnt is kept zero-filled
+    int32_t* hist = nullptr; int64_t hist_cap = 0;
+    int32_t* off = nullptr; int32_t* out = nullptr; float* u = nullptr; int rows_cap = 0;
+    float* probs = nullptr; int64_t probs_elems = 0;
+};
+
 struct nvl_local_group {
     std::mutex mu;
     std::condition_variable cv;
@@ -100,6 +109,8 @@ struct nvl_model {
     float* sk_part = nullptr; int sk_max_slices = 4; int pending_slices = 0, pending_rows = 0; float pending_alpha = 1.f; const float* pending_part = nullptr;
     // per-call metadata (one pinned host block mirrored on the device)
     int32_t* meta_host = nullptr; int32_t* meta_dev = nullptr; int64_t meta_ints = 0;
+    SampleBufs samp;             // nvl_sample scratch
+    int last_rows = 0;           // logits rows the last forward left in `logits`
     int32_t* ring = nullptr; int64_t ring_ints = 0;   // nvl_decode_greedy: [steps][seqs] tokens on the device
     // debug
     bool keep_hidden = false; float* hidden = nullptr; int64_t hidden_tokens = 0; int hidden_last_M = 0;

@@ -48,6 +48,10 @@ void* dmalloc_bytes(int64_t n) {
     return p;
 }
 void dfree(void* p) { if (p) (void)hipFree(p); }
+void free_sample_bufs(SampleBufs& b) {
+    dfree(b.work); dfree(b.cnt); dfree(b.hist); dfree(b.off); dfree(b.out); dfree(b.u); dfree(b.probs);
+    b = SampleBufs{};
+}
 
 bool is_1d(int kind) {
     switch (kind) {
@@ -132,6 +136,7 @@ extern "C" int nvl_sizeof(int which) {
         case 0: return (int)sizeof(nvl_model_config);
         case 1: return (int)sizeof(nvl_runtime_opts);
         case 2: return (int)sizeof(nvl_stats);
+        case 3: return (int)sizeof(nvl_sampling_params);
         default: return -1;
     }
 }
@@ -228,6 +233,7 @@ extern "C" void nvl_destroy(nvl_model* m) {
     dfree(m->xn_last); dfree(m->logits); dfree(m->argmax_dev); dfree(m->argmax_pval); dfree(m->argmax_pidx); dfree(m->router_logits); dfree(m->expert_ids);
     dfree(m->expert_w); dfree(m->seg_start); dfree(m->moe_counts); dfree(m->moe_cursor); dfree(m->moe_tile_map); dfree(m->moe_n_mtiles); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo);
     dfree(m->meta_dev); dfree(m->hidden); dfree(m->sk_part); dfree(m->tp_part); dfree(m->ring);
+    free_sample_bufs(m->samp);
     if (m->tp_comm) (void)ncclCommDestroy((ncclComm_t)m->tp_comm);
     if (m->tp_local) {
         bool last;
@@ -1071,6 +1077,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
                       m->argmax_dev);
         NVL_HIP(hipGetLastError());
     }
+    m->last_rows = rows;
     return rows;
 }
 
@@ -1300,8 +1307,106 @@ extern "C" int nvl_reset_stats(nvl_model* m) {
 // =================================================================================================
 // runner: ModelRunner.Run semantics (tensor_model_runner.go:55-97)
 // =================================================================================================
+// =================================================================================================
+// on-device sampling: tensor.SampleWithHistory, sampling.go:33-102
+// =================================================================================================
+namespace {
+// rows of device logits -> sampled ids on the host.  `err` receives the reason when the arguments are refused.
+int sample_rows(hipStream_t st, SampleBufs& b, const float* logits_dev, int64_t ld, int rows, int V,
+                const nvl_sampling_params* sp, const int32_t* const* hist_ptrs, const int32_t* hist_lens,
+                const float* uniforms, int32_t* out_host, float* probs_host, std::string& err) {
+    if (rows <= 0 || V <= 0 || !sp || !uniforms || !out_host) { err = "null/empty arguments"; return NVL_ERR_INVALID; }
+    if (!(sp->repetition_penalty == sp->repetition_penalty) || !(sp->temperature == sp->temperature) || !(sp->top_p == sp->top_p)) {
+        err = "NaN sampling parameter"; return NVL_ERR_INVALID;
+    }
+    if (sp->repetition_penalty == 0.f) { err = "repetition_penalty 0 (the reference would divide by zero)"; return NVL_ERR_INVALID; }
+    std::vector<int32_t> off((size_t)rows + 1, 0), hist;
+    for (int i = 0; i < rows; i++) {
+        const int n = (hist_ptrs && hist_lens && hist_ptrs[i]) ? hist_lens[i] : 0;
+        if (n < 0) { err = "negative history length"; return NVL_ERR_INVALID; }
+        for (int j = 0; j < n; j++) {
+            if (hist_ptrs[i][j] < 0) { err = "negative token id in the history (the reference would panic)"; return NVL_ERR_INVALID; }
+            hist.push_back(hist_ptrs[i][j]);
+        }
+        off[(size_t)i + 1] = (int32_t)hist.size();
+        if (!(uniforms[i] >= 0.f && uniforms[i] <= 1.f)) { err = "uniform draw outside [0, 1]"; return NVL_ERR_INVALID; }
+    }
+    const int64_t elems = (int64_t)rows * V;
+    if (elems > b.elems) {
+        dfree(b.work); dfree(b.cnt);
+        b.work = dmalloc<float>(elems); b.cnt = dmalloc<int32_t>(elems); b.elems = elems;
+        NVL_HIP(hipMemsetAsync(b.cnt, 0, (size_t)elems * 4, st));
+    }
+    if ((int64_t)hist.size() > b.hist_cap) {
+        dfree(b.hist); b.hist_cap = round_up((int64_t)hist.size(), 4096); b.hist = dmalloc<int32_t>(b.hist_cap);
+    }
+    if (rows > b.rows_cap) {
+        dfree(b.off); dfree(b.out); dfree(b.u);
+        b.rows_cap = (int)round_up(rows, 64);
+        b.off = dmalloc<int32_t>(b.rows_cap + 1); b.out = dmalloc<int32_t>(b.rows_cap); b.u = dmalloc<float>(b.rows_cap);
+    }
+    if (probs_host && elems > b.probs_elems) { dfree(b.probs); b.probs = dmalloc<float>(elems); b.probs_elems = elems; }
+    if (!hist.empty()) NVL_HIP(hipMemcpyAsync(b.hist, hist.data(), hist.size() * 4, hipMemcpyHostToDevice, st));
+    NVL_HIP(hipMemcpyAsync(b.off, off.data(), off.size() * 4, hipMemcpyHostToDevice, st));
+    NVL_HIP(hipMemcpyAsync(b.u, uniforms, (size_t)rows * 4, hipMemcpyHostToDevice, st));
+    SampleArgs a{};
+    a.logits = logits_dev; a.ld = ld; a.work = b.work; a.cnt = b.cnt; a.hist = b.hist; a.hist_off = b.off;
+    a.uniforms = b.u; a.out = b.out; a.probs_out = probs_host ? b.probs : nullptr; a.ldp = V;
+    a.V = V; a.top_k = sp->top_k; a.temperature = sp->temperature; a.top_p = sp->top_p; a.rep_penalty = sp->repetition_penalty;
+    hipLaunchKernelGGL(sample_row_kernel, dim3(rows), dim3(SAMPLE_THREADS), 0, st, a);
+    NVL_HIP(hipGetLastError());
+    NVL_HIP(hipMemcpyAsync(out_host, b.out, (size_t)rows * 4, hipMemcpyDeviceToHost, st));
+    if (probs_host) NVL_HIP(hipMemcpyAsync(probs_host, b.probs, (size_t)elems * 4, hipMemcpyDeviceToHost, st));
+    NVL_HIP(hipStreamSynchronize(st));   // (also keeps the host vectors alive until the copies are done)
+    return NVL_OK;
+}
+}  // namespace
+
+extern "C" int nvl_sample(nvl_model* m, int n_rows, const nvl_sampling_params* params, const int32_t* const* history_ptrs,
+                          const int32_t* history_lens, const float* uniforms, int32_t* out_tokens) {
+    if (!m) return NVL_ERR_INVALID;
+    if (!m->finalized) return fail(m, NVL_ERR_STATE, "nvl_sample: model not finalized");
+    if (n_rows <= 0 || n_rows > m->last_rows) return fail(m, NVL_ERR_INVALID, "nvl_sample: n_rows exceeds the logits rows of the last forward");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    std::string err;
+    const int rc = sample_rows(m->stream, m->samp, m->logits, m->Vpad, n_rows, m->V, params, history_ptrs, history_lens,
+                               uniforms, out_tokens, nullptr, err);
+    return rc ? fail(m, rc, "nvl_sample: " + err) : NVL_OK;
+    NVL_CATCH(m)
+}
+
+namespace {
+int runner_impl(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* const* token_ptrs,
+                const int32_t* token_lens, int is_prefill, int32_t* next_tokens, float* logits_out,
+                const nvl_sampling_params* sp, const float* uniforms);
+}
 extern "C" int nvl_runner_run(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* const* token_ptrs,
                               const int32_t* token_lens, int is_prefill, int32_t* next_tokens, float* logits_out) {
+    return runner_impl(m, n_seqs, seq_ids, token_ptrs, token_lens, is_prefill, next_tokens, logits_out, nullptr, nullptr);
+}
+extern "C" int nvl_runner_run_sampled(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* const* token_ptrs,
+                                      const int32_t* token_lens, int is_prefill, const nvl_sampling_params* params,
+                                      const float* uniforms, int32_t* next_tokens) {
+    if (!m) return NVL_ERR_INVALID;
+    if (!params || !uniforms) return fail(m, NVL_ERR_INVALID, "nvl_runner_run_sampled: null sampling arguments");
+    return runner_impl(m, n_seqs, seq_ids, token_ptrs, token_lens, is_prefill, next_tokens, nullptr, params, uniforms);
+}
+namespace {
+// after a forward over the sequences `who` (indices into the caller's arrays; logits rows in that order): replace the
+// greedy ids by SampleWithHistory(logits, seq.TokenIDs, params) (tensor_model_runner.go:93)
+int runner_sample(nvl_model* m, const std::vector<int>& who, const int32_t* const* token_ptrs, const int32_t* token_lens,
+                  const nvl_sampling_params* sp, const float* uniforms, int32_t* next_tokens) {
+    std::vector<const int32_t*> hp(who.size()); std::vector<int32_t> hl(who.size()), out(who.size()); std::vector<float> u(who.size());
+    for (size_t j = 0; j < who.size(); j++) { hp[j] = token_ptrs[who[j]]; hl[j] = token_lens[who[j]]; u[j] = uniforms[who[j]]; }
+    const int rc = nvl_sample(m, (int)who.size(), sp, hp.data(), hl.data(), u.data(), out.data());
+    if (rc) return rc;
+    for (size_t j = 0; j < who.size(); j++) next_tokens[who[j]] = out[j];
+    return NVL_OK;
+}
+int runner_impl(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* const* token_ptrs,
+                const int32_t* token_lens, int is_prefill, int32_t* next_tokens, float* logits_out,
+                const nvl_sampling_params* sp, const float* uniforms) {
     if (!m) return NVL_ERR_INVALID;
     if (!m->finalized) return fail(m, NVL_ERR_STATE, "nvl_runner_run: model not finalized");
     if (n_seqs <= 0 || !seq_ids || !token_ptrs || !token_lens || !next_tokens)
@@ -1335,6 +1440,11 @@ extern "C" int nvl_runner_run(nvl_model* m, int n_seqs, const int64_t* seq_ids, 
             next_tokens[dec[base + j]] = out[j];
             if (logits_out) memcpy(logits_out + (size_t)dec[base + j] * V, &lg[j * (size_t)V], (size_t)V * 4);
         }
+        if (sp) {
+            const std::vector<int> who(dec.begin() + (long)base, dec.begin() + (long)(base + n));
+            const int rs = runner_sample(m, who, token_ptrs, token_lens, sp, uniforms, next_tokens);
+            if (rs) return rs;
+        }
     }
     // ---- prefill group: discard the cache, run the whole history from position 0 (:63-66,75);
     // packed into forward calls of at most max_batch_tokens; a longer history is fed in chunks.
@@ -1367,6 +1477,10 @@ extern "C" int nvl_runner_run(nvl_model* m, int n_seqs, const int64_t* seq_ids, 
             }
             next_tokens[i] = out;
             if (logits_out) memcpy(logits_out + (size_t)i * V, lg.data(), (size_t)V * 4);
+            if (sp) {
+                const int rs = runner_sample(m, std::vector<int>{i}, token_ptrs, token_lens, sp, uniforms, next_tokens);
+                if (rs) return rs;
+            }
             k++;
             continue;
         }
@@ -1379,8 +1493,13 @@ extern "C" int nvl_runner_run(nvl_model* m, int n_seqs, const int64_t* seq_ids, 
             next_tokens[who[j]] = out[j];
             if (logits_out) memcpy(logits_out + (size_t)who[j] * V, &lg[j * (size_t)V], (size_t)V * 4);
         }
+        if (sp) {
+            const int rs = runner_sample(m, who, token_ptrs, token_lens, sp, uniforms, next_tokens);
+            if (rs) return rs;
+        }
     }
     return NVL_OK;
 }
+}  // namespace
 
 #include "ops_impl.h"

@@ -326,6 +326,23 @@ extern "C" int nvl_op_argmax(int device, const float* x, int rows, int cols, int
 
 // Tuning/measurement entry: time one projection GEMM shape on the device with HIP events.
 // epi: 0 STORE(fp32 out) 1 RESID 2 SWIGLU 3 GELU; force_bnt/force_ksplit = 0 -> automatic.
+extern "C" int nvl_op_sample(int device, const float* logits, int rows, int V, const nvl_sampling_params* params,
+                             const int32_t* const* history_ptrs, const int32_t* history_lens, const float* uniforms,
+                             int32_t* out_tokens, float* probs_out) {
+    if (!logits || rows <= 0 || V <= 0) return op_fail("nvl_op_sample: bad arguments");
+    OP_TRY
+    OpCtx cx(device, NVL_PRECISION_F32);
+    float* L = cx.up_f32(logits, (int64_t)rows * V);
+    SampleBufs b;
+    std::string err;
+    int rc;
+    try { rc = sample_rows(cx.m.stream, b, L, V, rows, V, params, history_ptrs, history_lens, uniforms, out_tokens, probs_out, err); }
+    catch (...) { free_sample_bufs(b); throw; }
+    free_sample_bufs(b);
+    return rc ? op_fail("nvl_op_sample: " + err, rc) : NVL_OK;
+    OP_CATCH
+}
+
 extern "C" int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int force_ksplit, int iters,
                               float* avg_us) {
     if (!avg_us || M <= 0 || N <= 0 || K % 64 || iters <= 0) return op_fail("nvl_bench_gemm: bad arguments");

@@ -163,6 +163,17 @@ class HipTransformerModel:
             out += [int(t) for t in self.decode_greedy([seq_id], [out[0]], max_tokens - 1)[:, 0]]
         return out
 
+    def sample(self, histories, uniforms, *, temperature=1.0, top_p=1.0, top_k=0, repetition_penalty=1.2):
+        """nvl_sample: tensor.SampleWithHistory on the logits rows the last forward left on the device."""
+        from .ops import _histories
+        n = len(uniforms)
+        ptrs, lens, keep = _histories(histories, n)
+        u = np.ascontiguousarray(uniforms, dtype=np.float32)
+        out = np.empty(n, np.int32)
+        sp = L.sampling_params(temperature, top_p, top_k, repetition_penalty)
+        L.check(self.lib.nvl_sample(self.h, n, C.byref(sp), ptrs, _ptr(lens), _ptr(u), _ptr(out)), self.h)
+        return out
+
     # -- debug / parity taps ------------------------------------------------------------------------
     def set_debug(self, keep_hidden: bool):
         L.check(self.lib.nvl_set_debug(self.h, int(keep_hidden)), self.h)

@@ -100,3 +100,26 @@ def argmax(x, device=0):                                       # argmax cmd/ask/
     out = np.empty(x.shape[0], np.int32)
     L.check(L.lib().nvl_op_argmax(device, _p(x), x.shape[0], x.shape[1], _p(out)))
     return out
+
+
+def _histories(histories, rows):
+    """-> (pointer array, int32 lengths, keep-alive list) for `rows` token histories (None = no history)."""
+    arrs = [np.ascontiguousarray([] if h is None else h, dtype=np.int32) for h in (histories or [None] * rows)]
+    ptrs = (C.c_void_p * rows)(*[a.ctypes.data_as(C.c_void_p).value if a.size else None for a in arrs])
+    lens = np.asarray([a.size for a in arrs], np.int32)
+    return ptrs, lens, arrs
+
+
+def sample_with_history(logits, histories, uniforms, *, temperature=1.0, top_p=1.0, top_k=0, repetition_penalty=1.2,
+                        return_probs=False, device=0):        # SampleWithHistory sampling.go:33, u = rand.Float32()
+    lg = _f(logits)
+    if lg.ndim == 1:
+        lg = lg[None]
+    rows, V = lg.shape
+    ptrs, lens, keep = _histories(histories, rows)
+    u = _f(uniforms).reshape(rows)
+    out = np.empty(rows, np.int32)
+    probs = np.empty((rows, V), np.float32) if return_probs else None
+    sp = L.sampling_params(temperature, top_p, top_k, repetition_penalty)
+    L.check(L.lib().nvl_op_sample(device, _p(lg), rows, V, C.byref(sp), ptrs, _p(lens), _p(u), _p(out), _p(probs)))
+    return (out, probs) if return_probs else out

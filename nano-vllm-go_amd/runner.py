@@ -31,10 +31,10 @@ class Sequence:
 class HipModelRunner:
     """ModelRunner{Run, Close} (nanovllm/model_runner.go:9-16) with TensorModelRunner's extra methods.
 
-    Run returns greedy token ids (cmd/ask/main.go:389-402).  The reference's Run samples with
-    tensor.SampleWithHistory on the host (tensor_model_runner.go:93); callers that want that pass
-    `return_logits=True` and sample the returned last-row logits themselves — sampling stays host
-    side."""
+    run() returns greedy token ids (cmd/ask/main.go:389-402), optionally with the last-row logits for host-side
+    sampling.  run_sampled() is the reference's Run proper: tensor.SampleWithHistory(logits, seq.TokenIDs,
+    defaultSampling) (tensor_model_runner.go:93) on the device, with the rand.Float32() draws supplied by the
+    caller (one per sequence, in order) so the host keeps its own RNG stream."""
 
     def __init__(self, model: HipTransformerModel):
         self.model = model
@@ -65,6 +65,24 @@ class HipModelRunner:
                 self.model.h)
         toks = [int(t) for t in out]
         return (toks, logits) if return_logits else toks
+
+    def run_sampled(self, seqs, is_prefill: bool, uniforms):                  # tensor_model_runner.go:55-97 incl. :93
+        n = len(seqs)
+        if n == 0:
+            return []
+        ids = np.asarray([s.seq_id for s in seqs], np.int64)
+        arrs = [np.ascontiguousarray(s.token_ids, dtype=np.int32) for s in seqs]
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data_as(C.c_void_p).value for a in arrs])
+        lens = np.asarray([a.size for a in arrs], np.int32)
+        u = np.ascontiguousarray(uniforms, dtype=np.float32)
+        assert u.size == n
+        out = np.empty(n, np.int32)
+        sp = L.sampling_params(**self.default_sampling)
+        L.check(self.lib.nvl_runner_run_sampled(self.model.h, n, ids.ctypes.data_as(C.c_void_p), ptrs,
+                                                lens.ctypes.data_as(C.c_void_p), int(bool(is_prefill)), C.byref(sp),
+                                                u.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)),
+                self.model.h)
+        return [int(t) for t in out]
 
     def clear_cache(self, seq_id: int):                                        # :100-104
         self.model.seq_close(seq_id)

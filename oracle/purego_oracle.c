@@ -162,6 +162,78 @@ static float* concat_seq(const float* t1, int s1, const float* t2, int s2, int h
     return r;
 }
 
+/* ---- sampling.go ---- */
+typedef struct { int idx; float prob; } po_iprob;
+static int po_iprob_desc(const void* a, const void* b) {           /* sampling.go:143-145,172-174 (ties: by index) */
+    const po_iprob *x = (const po_iprob*)a, *y = (const po_iprob*)b;
+    if (x->prob > y->prob) return -1;
+    if (x->prob < y->prob) return 1;
+    return x->idx - y->idx;
+}
+int po_sample_with_history(const float* logits, int n, const int32_t* prev, int n_prev, float temperature,
+                           float top_p, int top_k, float rep_penalty, float u, float* probs_out) {
+    float* l = (float*)malloc((size_t)n * sizeof(float));
+    float* probs = (float*)malloc((size_t)n * sizeof(float));
+    po_iprob* ind = (po_iprob*)malloc((size_t)n * sizeof(po_iprob));
+    memcpy(l, logits, (size_t)n * sizeof(float));
+    /* repetition penalty (:43-68): counts weighted 3 for the last 10 history tokens */
+    if (rep_penalty != 1.0f && n_prev > 0) {
+        int* counts = (int*)calloc((size_t)n, sizeof(int));
+        for (int i = 0; i < n_prev; i++) {
+            const int w = i >= n_prev - 10 ? 3 : 1;
+            if (prev[i] >= 0 && prev[i] < n) counts[prev[i]] += w;
+        }
+        for (int t = 0; t < n; t++) {
+            if (!counts[t]) continue;
+            const float penalty = rep_penalty * (float)counts[t];
+            if (l[t] > 0) l[t] /= penalty; else l[t] *= penalty;
+        }
+        free(counts);
+    }
+    if (temperature > 0 && temperature != 1.0f)                     /* :71-75 */
+        for (int i = 0; i < n; i++) l[i] /= temperature;
+    /* softmax (:105-127) */
+    float mx = l[0];
+    for (int i = 1; i < n; i++) if (l[i] > mx) mx = l[i];
+    float sum = 0.f;
+    for (int i = 0; i < n; i++) { probs[i] = (float)exp((double)(l[i] - mx)); sum += probs[i]; }
+    for (int i = 0; i < n; i++) probs[i] /= sum;
+    if (top_k > 0 && top_k < n) {                                   /* :78-80, :130-156 */
+        for (int i = 0; i < n; i++) { ind[i].idx = i; ind[i].prob = probs[i]; }
+        qsort(ind, (size_t)n, sizeof(po_iprob), po_iprob_desc);
+        memset(probs, 0, (size_t)n * sizeof(float));
+        for (int i = 0; i < top_k && i < n; i++) probs[ind[i].idx] = ind[i].prob;
+    }
+    if (top_p < 1.0f) {                                             /* :83-85, :159-195 */
+        for (int i = 0; i < n; i++) { ind[i].idx = i; ind[i].prob = probs[i]; }
+        qsort(ind, (size_t)n, sizeof(po_iprob), po_iprob_desc);
+        float cum = 0.f;
+        int cutoff = n;
+        for (int i = 0; i < n; i++) {
+            cum += ind[i].prob;
+            if (cum >= top_p) { cutoff = i + 1; break; }
+        }
+        memset(probs, 0, (size_t)n * sizeof(float));
+        for (int i = 0; i < cutoff; i++) probs[ind[i].idx] = ind[i].prob;
+    }
+    sum = 0.f;                                                      /* :88-96 */
+    for (int i = 0; i < n; i++) sum += probs[i];
+    if (sum > 0) for (int i = 0; i < n; i++) probs[i] /= sum;
+    if (probs_out) memcpy(probs_out, probs, (size_t)n * sizeof(float));
+    /* sampleMultinomial (:198-217): first index with cum >= r (sort.Search) */
+    float c = 0.f, last = 0.f;
+    for (int i = 0; i < n; i++) last += probs[i];
+    const float r = u * last;
+    int idx = n;
+    for (int i = 0; i < n; i++) {
+        c = (i == 0) ? probs[0] : c + probs[i];
+        if (c >= r) { idx = i; break; }
+    }
+    if (idx >= n) idx = n - 1;
+    free(l); free(probs); free(ind);
+    return idx;
+}
+
 int po_argmax(const float* data, int n) { /* cmd/ask/main.go:389-402 */
     if (n == 0) return 0;
     int mi = 0;

@@ -126,6 +126,12 @@ void po_gqa_core(const float* q, const float* k, const float* v, int nH, int nKV
 void po_moe(const float* x, const float* router, const float* w_in, const float* w_out,
             int rows, int hidden, int n_experts, int top_k, int inter, float* y);
 
+/* SampleWithHistory (sampling.go:33-102) with the rand.Float32() draw of sampleMultinomial (:205) passed in as `u`.
+ * Same sequential fp32 sums, exp in double.  sort.Slice is unstable in the reference; ties are ordered by index here.
+ * probs_out (optional, [n]) receives the renormalised distribution; returns the sampled index. */
+int po_sample_with_history(const float* logits, int n, const int32_t* prev, int n_prev, float temperature,
+                           float top_p, int top_k, float rep_penalty, float u, float* probs_out);
+
 /* ---- load-time layout contract (generic_loader.go) ---- */
 void po_transpose(const float* t, float* out, int m, int n);                       /* tensor.go:112-125 */
 void po_split_gpt2_qkv(const float* qkv, int hidden, float* q, float* k, float* v);/* generic_loader.go:674-702 */

@@ -76,6 +76,8 @@ def lib():
         L.po_forward_with_cache.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_void_p]
         L.po_argmax.argtypes = [C.c_void_p, C.c_int]
+        L.po_sample_with_history.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int,
+                                             C.c_float, C.c_float, C.c_void_p]
         L.po_matmul.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3
         L.po_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int]
         L.po_softmax_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -213,6 +215,17 @@ class OracleModel:
 def argmax(x) -> int:
     a = _f32(x)
     return int(lib().po_argmax(_p(a), a.size))
+
+
+def sample_with_history(logits, previous_tokens, u, *, temperature=1.0, top_p=1.0, top_k=0, repetition_penalty=1.2,
+                        return_probs=False):
+    """SampleWithHistory (sampling.go:33-102) with rand.Float32() := u.  -> index [, final probs]."""
+    a = _f32(logits).reshape(-1)
+    prev = np.ascontiguousarray([] if previous_tokens is None else previous_tokens, dtype=np.int32)
+    probs = np.empty(a.size, np.float32)
+    idx = lib().po_sample_with_history(_p(a), a.size, _p(prev) if prev.size else None, prev.size, temperature, top_p,
+                                       top_k, repetition_penalty, u, _p(probs))
+    return (int(idx), probs) if return_probs else int(idx)
 
 
 def matmul(a, b):

@@ -112,3 +112,42 @@ def test_oracle_reports_the_reference_panics(oracle, pkg):
         om.forward_with_cache([1] * 17, om.new_cache(), 0)           # rope.go:84-86
     with pytest.raises(RuntimeError):
         om.forward_with_cache([cfg["vocab_size"]], om.new_cache(), 0)   # index out of range in embedWithOffset
+
+
+def test_sample_with_history_known_answers(oracle):
+    """sampling.go:33-102 on a case small enough to work out by hand (numpy float64 as the independent check)."""
+    logits = np.array([2.0, 1.0, 0.0, -1.0, 0.5], np.float32)
+    hist = [0, 0, 3]                              # all within the last 10: weight 3 each -> counts {0: 6, 3: 3}
+    l = logits.astype(np.float64).copy()
+    l[0] = l[0] / (1.2 * 6)                       # positive logit: divided (sampling.go:61)
+    l[3] = l[3] * (1.2 * 3)                       # negative logit: multiplied (:63)
+    l /= 0.5                                      # temperature
+    p = np.exp(l - l.max()); p /= p.sum()
+    idx, got = oracle.sample_with_history(logits, hist, 0.0, temperature=0.5, repetition_penalty=1.2, return_probs=True)
+    assert np.allclose(got, p, atol=1e-6) and idx == 0                     # u = 0 -> first index (sort.Search)
+    # the CDF walk: u just below / above a step
+    cum = np.cumsum(p)
+    assert oracle.sample_with_history(logits, hist, float(cum[1] - 1e-4), temperature=0.5) == 1
+    assert oracle.sample_with_history(logits, hist, float(cum[1] + 1e-4), temperature=0.5) == 2
+    # top-k keeps the k largest, top-p the shortest descending prefix reaching p; then renormalise (:88-96)
+    order = np.argsort(-p)
+    _, pk = oracle.sample_with_history(logits, hist, 0.3, temperature=0.5, top_k=2, return_probs=True)
+    want = np.zeros_like(p); want[order[:2]] = p[order[:2]]; want /= want.sum()
+    assert np.allclose(pk, want, atol=1e-6)
+    cs = np.cumsum(p[order]); cut = int(np.argmax(cs >= 0.8)) + 1
+    _, pp = oracle.sample_with_history(logits, hist, 0.3, temperature=0.5, top_p=0.8, return_probs=True)
+    want = np.zeros_like(p); want[order[:cut]] = p[order[:cut]]; want /= want.sum()
+    assert np.allclose(pp, want, atol=1e-6)
+    # older history counts once, the last ten three times (:46-52); ids >= V are skipped (:57)
+    long_hist = [1] + [4] * 10 + [99]
+    _, pl = oracle.sample_with_history(logits, long_hist, 0.3, return_probs=True)
+    l = logits.astype(np.float64).copy()
+    l[1] /= 1.2 * 1
+    l[4] /= 1.2 * (9 * 3 + 1)                     # positions 1..10 hold token 4; the last ten positions are 2..11
+    q = np.exp(l - l.max()); q /= q.sum()
+    assert np.allclose(pl, q, atol=1e-6)
+    # top_k = 1 is greedy whatever u is; T <= 0 leaves the logits unscaled (:71)
+    assert all(oracle.sample_with_history(logits, None, u, top_k=1) == 0 for u in (0.0, 0.5, 0.999))
+    _, p0 = oracle.sample_with_history(logits, None, 0.5, temperature=0.0, repetition_penalty=1.0, return_probs=True)
+    e = np.exp(logits.astype(np.float64) - 2.0)
+    assert np.allclose(p0, e / e.sum(), atol=1e-6)
