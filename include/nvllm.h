@@ -75,8 +75,15 @@ typedef struct nvl_runtime_opts {
     int32_t max_batch_tokens;  /* largest sum(seq_lens) one nvl_forward call may carry             */
     int32_t tp_rank, tp_size;  /* tensor-parallel shard of this process (1 = none); consumer of the
                                   reference's inert Config.TensorParallelSize (nanovllm/config.go:61) */
-    int32_t reserved[2];       /* reserved[0] = 1 with tp_size = 1: diagnostics — run the tensor-parallel
-                                  projection + all-reduce path on a one-rank group (needs nvl_tp_init) */
+    int32_t tp_force_single;   /* 1 with tp_size = 1: diagnostics — run the tensor-parallel projection +
+                                  all-reduce path on a one-rank group (needs nvl_tp_init)             */
+    int32_t kv_num_blocks;     /* > 0: PAGED KV — a pool of this many blocks addressed through the host's block
+                                  tables (nanovllm/block_manager.go, Sequence.BlockTable): nvl_forward_paged /
+                                  nvl_runner_run_paged; the slot calls (nvl_seq_*, nvl_forward) are refused.
+                                  0: one contiguous slab per sequence slot                              */
+    int32_t kv_block_size;     /* tokens per block in paged mode: 0 = 256 (Sequence.BlockSize, sequence.go:51);
+                                  a multiple of 64                                                     */
+    int32_t reserved;
 } nvl_runtime_opts;
 
 typedef struct nvl_model nvl_model;
@@ -176,6 +183,27 @@ enum {
 int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* tokens,
                 const int32_t* seq_lens, const int32_t* pos_offsets, uint32_t flags,
                 float* logits_out, int32_t* argmax_out);
+
+/* ---- paged KV: the host's block manager owns the cache ---- */
+/* One forward pass like nvl_forward, for a model created with kv_num_blocks > 0.  The KV cache of sequence i is the
+ * block list block_tables[table_offsets[i] .. table_offsets[i+1]) (Sequence.BlockTable, sequence.go:23): position p
+ * lives in its block p / block_size at row p % block_size.  pos_offsets[i] tokens are already cached — after a
+ * prefix-cache hit that is Sequence.NumCachedTokens (block_manager.go:128-203), in decode len-1 — and only
+ * seq_lens[i] new tokens are computed and written; blocks may be shared between sequences (same prefix), including
+ * within one call.  The table must cover pos_offsets[i] + seq_lens[i] tokens.  The library keeps no per-sequence
+ * state in this mode. */
+int nvl_forward_paged(nvl_model* m, int n_seqs, const int32_t* tokens, const int32_t* seq_lens,
+                      const int32_t* pos_offsets, const int32_t* block_tables, const int32_t* table_offsets,
+                      uint32_t flags, float* logits_out, int32_t* argmax_out);
+/* ModelRunner.Run for a block-table-aware runner: prefill computes tokens [num_cached_tokens[i], len) of each
+ * sequence (all of them when num_cached_tokens is NULL; a fully cached prompt recomputes its last token), decode the
+ * last token at len-1.  Greedy ids in next_tokens; sample with nvl_sample afterwards if wanted. */
+int nvl_runner_run_paged(nvl_model* m, int n_seqs, const int32_t* const* token_ptrs, const int32_t* token_lens,
+                         const int32_t* num_cached_tokens, const int32_t* const* block_table_ptrs,
+                         const int32_t* block_table_lens, int is_prefill, int32_t* next_tokens, float* logits_out);
+/* Debug/parity for paged mode: the K and V rows of `n_tokens` positions of one block list, as nvl_get_kv. */
+int nvl_get_kv_paged(nvl_model* m, const int32_t* block_table, int n_blocks, int n_tokens, int layer, float* k_out,
+                     float* v_out);
 
 /* The greedy generation loop of cmd/ask (generateResponse, cmd/ask/main.go:315-360, without its EOS/"User" stop: the
  * caller truncates) for a batch, as ONE call: n_steps decode steps of one token per sequence starting from

@@ -9,4 +9,4 @@ the reference's TransformerModel / TensorModelRunner interface.  It never import
 from . import _lib, config, dist, ops, synth  # noqa: F401
 from ._lib import NvlError, declared_symbols, lib  # noqa: F401
 from .model import HipTransformerModel  # noqa: F401
-from .runner import HipModelRunner, Sequence  # noqa: F401
+from .runner import HipModelRunner, HipPagedModelRunner, Sequence  # noqa: F401

@@ -58,7 +58,8 @@ class ModelConfigC(C.Structure):
 class RuntimeOptsC(C.Structure):
     _fields_ = [("device", C.c_int32), ("precision", C.c_int32), ("max_seqs", C.c_int32),
                 ("max_batch_tokens", C.c_int32), ("tp_rank", C.c_int32), ("tp_size", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("tp_force_single", C.c_int32), ("kv_num_blocks", C.c_int32), ("kv_block_size", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class StatsC(C.Structure):
@@ -110,6 +111,9 @@ def lib():
     L.nvl_seq_close_all.argtypes = [vp]
     L.nvl_forward.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_uint32, vp, vp]
     L.nvl_decode_greedy.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
+    L.nvl_forward_paged.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]
+    L.nvl_runner_run_paged.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp]
+    L.nvl_get_kv_paged.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.nvl_set_debug.argtypes = [vp, C.c_int]
     L.nvl_get_hidden.argtypes = [vp, C.c_int, vp, i64]
     L.nvl_get_kv.argtypes = [vp, i64, C.c_int, vp, vp]

@@ -27,14 +27,16 @@ struct AttnArgs {
     int q_stride;
     void* out;            // [tokens][out_stride] (bf16: fragment-major, fp32: row-major); head h at column h*HD
     int out_stride;
-    const void* kcache;   // layer base; (slot, kvh) at slot*slot_stride + kvh*Tmax*HD; [Tmax][HD]
+    const void* kcache;   // layer base; (block, kvh) at block*slot_stride + kvh*Tmax*HD; [Tmax][HD]
     const void* vcache;   // bf16: V^T [HD][Tmax]; f32: [Tmax][HD]
-    int64_t slot_stride;  // elements
-    int Tmax;
+    int64_t slot_stride;  // elements between consecutive KV blocks
+    int Tmax;             // tokens per KV block (a multiple of 64): the whole slot in slab mode, 256 in paged mode
     const int32_t* seq_tok_start;
     const int32_t* seq_len;
     const int32_t* seq_pos;
-    const int32_t* seq_slot;
+    const int32_t* blk_table;   // [sequence in the batch][tbl_stride] block ids (slab mode: one entry, the slot)
+    int tbl_stride;
+    int bs_shift;               // log2(Tmax) when it is a power of two, else -1 (then the kernels divide)
     int nH, nKV, group;
     float scale;
     // fused decode (attn_decode_bf16_kernel<.., FUSED>): q/k/v of the NEW token come straight from the fp32 output of
@@ -45,6 +47,9 @@ struct AttnArgs {
     const float* cos_t;   // [max_seq][HD] or NULL
     const float* sin_t;
 };
+
+// index of the KV block that holds key `key`
+__device__ __forceinline__ int kv_block_index(const AttnArgs& p, int key) { return p.bs_shift >= 0 ? (key >> p.bs_shift) : key / p.Tmax; }
 
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
@@ -59,7 +64,8 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
     const int S = p.seq_len[seq];
     const int R = S * p.group;                 // query rows of this (seq, kv head)
     if (qt * 64 >= R) return;
-    const int tok0 = p.seq_tok_start[seq], pos0 = p.seq_pos[seq], slot = p.seq_slot[seq];
+    const int tok0 = p.seq_tok_start[seq], pos0 = p.seq_pos[seq];
+    const int32_t* tbl = p.blk_table + (int64_t)seq * p.tbl_stride;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fq = lane & 15, fg = lane >> 4;
 
@@ -81,15 +87,17 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
     const int kmax = pos0 + last_row / p.group;
     const int n_kt = kmax / 64 + 1;
 
-    const bf16_t* kbase = (const bf16_t*)p.kcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
-    const bf16_t* vbase = (const bf16_t*)p.vcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
-
     f32x4 o[DT];
 #pragma unroll
     for (int d = 0; d < DT; d++) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
     for (int kt = 0; kt < n_kt; kt++) {
+        // the KV block holding this 64-key tile (64 | Tmax: a tile never straddles blocks)
+        const int bi = kv_block_index(p, kt * 64), krow0 = kt * 64 - bi * p.Tmax;
+        const int64_t blk_off = (int64_t)tbl[bi] * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
+        const bf16_t* kbase = (const bf16_t*)p.kcache + blk_off + (int64_t)krow0 * HD;     // K rows of the tile
+        const bf16_t* vbase = (const bf16_t*)p.vcache + blk_off + krow0;                    // V^T columns of the tile
         __syncthreads();
         // ---- stage K tile [64 keys][HD] and V^T tile [HD][64 keys] (register staged) ----
         {
@@ -97,13 +105,13 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
 #pragma unroll
             for (int c = tid; c < 64 * KCH; c += 256) {
                 const int r = c / KCH, cc = c % KCH;
-                const bf16x8 v = *(const bf16x8*)(kbase + (int64_t)(kt * 64 + r) * HD + cc * 8);
+                const bf16x8 v = *(const bf16x8*)(kbase + (int64_t)r * HD + cc * 8);
                 *(bf16x8*)(Ks + r * KROW + cc * 8) = v;
             }
 #pragma unroll
             for (int c = tid; c < HD * 8; c += 256) {
                 const int r = c >> 3, cc = c & 7;
-                const bf16x8 v = *(const bf16x8*)(vbase + (int64_t)r * p.Tmax + kt * 64 + cc * 8);
+                const bf16x8 v = *(const bf16x8*)(vbase + (int64_t)r * p.Tmax + cc * 8);
                 *(bf16x8*)(Vts + r * VROW + cc * 8) = v;
             }
         }
@@ -215,15 +223,14 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
     __shared__ float red_l[NW][16];
     __shared__ f32x4 red_o[NW][DT][64];
     const int seq = blockIdx.y, kvh = blockIdx.x;
-    const int tok = p.seq_tok_start[seq], pos0 = p.seq_pos[seq], slot = p.seq_slot[seq];
+    const int32_t* tbl = p.blk_table + (int64_t)seq * p.tbl_stride;
+    const int tok = p.seq_tok_start[seq], pos0 = p.seq_pos[seq];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fq = lane & 15, fg = lane >> 4;
     const bool row_ok = fq < p.group;
     const int head = kvh * p.group + (row_ok ? fq : 0);
     bf16x8 qf[KS];
     const int n_kt = pos0 / 64 + 1;
-    const bf16_t* kbase = (const bf16_t*)p.kcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
-    const bf16_t* vbase = (const bf16_t*)p.vcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
     // FUSED: the new token's K row (RoPE applied) as this lane's operand chunks, and its V values for this lane's d
     bf16x8 knew[KS];
     bf16_t vnew[DT];
@@ -253,6 +260,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
     // Each wave owns key tiles wave, wave+NW, ...; the loads of TWO of its tiles are issued before either is used
     // (a decode step is latency-bound: ~150 KB per workgroup), so sequences up to 2*NW*64 keys take one round trip.
     constexpr int NT2 = HD <= 64 ? 2 : 1;      // hd 128: one tile's operands already fill the register budget
+    // the block ids of this wave's first tiles do not depend on the sequence length: fetch them beside it, not after it
+    int first_blk[NT2];
+#pragma unroll
+    for (int h = 0; h < NT2; h++) first_blk[h] = tbl[min(kv_block_index(p, (wave + h * NW) * 64), p.tbl_stride - 1)];
     bf16x8 kf[NT2][4][KS];
     bf16x4 vlo[NT2][2][DT], vhi[NT2][2][DT];
     for (int kt0 = wave; kt0 < n_kt; kt0 += NT2 * NW) {
@@ -260,16 +271,21 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
         for (int h = 0; h < NT2; h++) {
             const int kt = kt0 + h * NW;
             if (kt >= n_kt) continue;
+            const int bi = kv_block_index(p, kt * 64), krow0 = kt * 64 - bi * p.Tmax;     // the KV block holding this tile
+            const int blk = kt0 == wave ? first_blk[h] : tbl[bi];
+            const int64_t blk_off = (int64_t)blk * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
+            const bf16_t* kbase = (const bf16_t*)p.kcache + blk_off + (int64_t)krow0 * HD;
+            const bf16_t* vbase = (const bf16_t*)p.vcache + blk_off + krow0;
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++)
-                    kf[h][t][ks] = *(const bf16x8*)(kbase + (int64_t)(kt * 64 + t * 16 + fq) * HD + ks * 32 + fg * 8);
+                    kf[h][t][ks] = *(const bf16x8*)(kbase + (int64_t)(t * 16 + fq) * HD + ks * 32 + fg * 8);
 #pragma unroll
             for (int u = 0; u < 2; u++)
 #pragma unroll
                 for (int d = 0; d < DT; d++) {
-                    const bf16_t* vr = vbase + (int64_t)(d * 16 + fq) * p.Tmax + kt * 64 + u * 32 + fg * 4;
+                    const bf16_t* vr = vbase + (int64_t)(d * 16 + fq) * p.Tmax + u * 32 + fg * 4;
                     vlo[h][u][d] = *(const bf16x4*)(vr);
                     vhi[h][u][d] = *(const bf16x4*)(vr + 16);
                 }
@@ -351,13 +367,15 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
     if (FUSED) {
         // append the new key/value to the slabs for the following steps — after every load of this step (which used
         // the register copies), so the loads above are not ordered behind these stores
+        int nblk, nrow;
+        kv_locate(tbl, 0, pos0, p.Tmax, nblk, nrow);
         if (wave == 0 && fq == 0) {      // lanes fg = 0..3 of column 0 hold all of K_new between them
-            bf16_t* kd = (bf16_t*)p.kcache + (int64_t)slot * p.slot_stride + ((int64_t)kvh * p.Tmax + pos0) * HD;
+            bf16_t* kd = (bf16_t*)p.kcache + (int64_t)nblk * p.slot_stride + ((int64_t)kvh * p.Tmax + nrow) * HD;
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) *(bf16x8*)(kd + ks * 32 + fg * 8) = knew[ks];
         }
         if (wave == 1 % NW && fg == 0) {  // lanes fq = 0..15 hold V_new[16d + fq]
-            bf16_t* vd = (bf16_t*)p.vcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD + pos0;
+            bf16_t* vd = (bf16_t*)p.vcache + (int64_t)nblk * p.slot_stride + (int64_t)kvh * p.Tmax * HD + nrow;
 #pragma unroll
             for (int d = 0; d < DT; d++) vd[(int64_t)(d * 16 + fq) * p.Tmax] = vnew[d];
         }
@@ -401,14 +419,16 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p, int HD) {
     const int kvh = head / p.group;
     const int tok = p.seq_tok_start[seq] + s_idx;
     const int T = p.seq_pos[seq] + s_idx + 1;     // keys 0..limit
-    const int slot = p.seq_slot[seq];
+    const int32_t* tbl = p.blk_table + (int64_t)seq * p.tbl_stride;
     const float* q = (const float*)p.q + (int64_t)tok * p.q_stride + head * HD;
-    const float* kb = (const float*)p.kcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
-    const float* vb = (const float*)p.vcache + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
+    auto kv_row = [&](const void* cache, int j) {       // row of key j: [block][kvh][Tmax][HD]
+        const int bi = j / p.Tmax;
+        return (const float*)cache + (int64_t)tbl[bi] * p.slot_stride + ((int64_t)kvh * p.Tmax + (j - bi * p.Tmax)) * HD;
+    };
 
     float lmax = -INFINITY;
     for (int j = tid; j < T; j += 256) {
-        const float* kr = kb + (int64_t)j * HD;
+        const float* kr = kv_row(p.kcache, j);
         float sum = 0.f;
         for (int d = 0; d < HD; d++) sum = fmaf(q[d], kr[d], sum);
         sum *= p.scale;
@@ -435,7 +455,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p, int HD) {
     float* op = (float*)p.out + (int64_t)tok * p.out_stride + head * HD;
     for (int d = tid; d < HD; d += 256) {
         float acc = 0.f;
-        for (int j = 0; j < T; j++) acc = fmaf(sc[j], vb[(int64_t)j * HD + d], acc);
+        for (int j = 0; j < T; j++) acc = fmaf(sc[j], kv_row(p.vcache, j)[d], acc);
         op[d] = acc;
     }
 }

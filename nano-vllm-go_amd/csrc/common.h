@@ -59,6 +59,15 @@ template <> __device__ __forceinline__ void act_store4<bf16_t>(bf16_t* base, int
     *(bf16x4*)(base + fm_index(r, k, K)) = o;
 }
 
+// ---- KV placement ---------------------------------------------------------------------------
+// A sequence's keys live in blocks of `bs` tokens named by its block table blk_table[tbl ...] (paged mode: the host's
+// 256-token blocks, block_manager.go; slab mode: ONE block spanning the whole slot).  Position pos -> (block, row).
+__device__ __forceinline__ void kv_locate(const int32_t* __restrict__ blk_table, int tbl, int pos, int bs, int& blk, int& row) {
+    const int bi = pos / bs;
+    blk = blk_table[tbl + bi];
+    row = pos - bi * bs;
+}
+
 // ---- wave reductions (64 lanes) ----------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -190,13 +190,16 @@ __global__ __launch_bounds__(256) void norm_row_kernel(float* __restrict__ x,
 // ---------------------------------------------------------------------------------------
 template <typename ActT, bool VT>
 __global__ void rope_kv_kernel(const float* __restrict__ qkv, int qkv_stride,
-                               const int32_t* __restrict__ tok_pos, const int32_t* __restrict__ tok_slot,
+                               const int32_t* __restrict__ tok_pos, const int32_t* __restrict__ tok_tbl,
+                               const int32_t* __restrict__ blk_table,
                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                ActT* __restrict__ q_out, int q_stride,
                                ActT* __restrict__ kcache, ActT* __restrict__ vcache,
                                int64_t slot_stride, int Tmax, int nH, int nKV, int HD) {
     const int t = blockIdx.x, h = blockIdx.y;
-    const int pos = tok_pos[t], slot = tok_slot[t];
+    const int pos = tok_pos[t];
+    int slot, row;                                   // KV block of this position and the row inside it
+    kv_locate(blk_table, tok_tbl[t], pos, Tmax, slot, row);
     const int half = HD >> 1;
     const float* src = qkv + (int64_t)t * qkv_stride + (int64_t)h * HD;
     for (int i = threadIdx.x; i < half; i += blockDim.x) {
@@ -214,17 +217,17 @@ __global__ void rope_kv_kernel(const float* __restrict__ qkv, int qkv_stride,
             ActIO<ActT>::st(d + i + half, y2);
         } else if (h < nH + nKV) {
             const int kvh = h - nH;
-            ActT* d = kcache + (int64_t)slot * slot_stride + ((int64_t)kvh * Tmax + pos) * HD;
+            ActT* d = kcache + (int64_t)slot * slot_stride + ((int64_t)kvh * Tmax + row) * HD;
             ActIO<ActT>::st(d + i, y1);
             ActIO<ActT>::st(d + i + half, y2);
         } else {
             const int kvh = h - nH - nKV;
             if (VT) {
                 ActT* d = vcache + (int64_t)slot * slot_stride + (int64_t)kvh * Tmax * HD;
-                ActIO<ActT>::st(d + (int64_t)i * Tmax + pos, y1);
-                ActIO<ActT>::st(d + (int64_t)(i + half) * Tmax + pos, y2);
+                ActIO<ActT>::st(d + (int64_t)i * Tmax + row, y1);
+                ActIO<ActT>::st(d + (int64_t)(i + half) * Tmax + row, y2);
             } else {
-                ActT* d = vcache + (int64_t)slot * slot_stride + ((int64_t)kvh * Tmax + pos) * HD;
+                ActT* d = vcache + (int64_t)slot * slot_stride + ((int64_t)kvh * Tmax + row) * HD;
                 ActIO<ActT>::st(d + i, y1);
                 ActIO<ActT>::st(d + i + half, y2);
             }

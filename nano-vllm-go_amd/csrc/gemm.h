@@ -37,7 +37,8 @@ enum GemmEpi {
 
 struct QkvEpi {             // EPI_QKV only
     const int32_t* tok_pos;
-    const int32_t* tok_slot;
+    const int32_t* tok_tbl;     // per token: where its sequence's block table starts in blk_table
+    const int32_t* blk_table;   // KV block ids (slab mode: the slot); Tmax tokens per block
     const float* cos_t;     // [max_seq][64] or NULL (no RoPE)
     const float* sin_t;
     bf16_t* q_out;          // [tokens][nH*64] row-major
@@ -156,10 +157,12 @@ __device__ __forceinline__ void epilogue_qkv_head(const GemmArgs& p, int m, int 
             t[j + TH / 2] = x2 * c + x1 * s;
         }
     }
+    int blk = 0, row = 0;
+    if (head >= q.nH) kv_locate(q.blk_table, q.tok_tbl[m], pos, q.Tmax, blk, row);
     if (head < q.nH + q.nKV) {
         bf16_t* dst = head < q.nH
             ? q.q_out + (int64_t)m * (q.nH * HD) + head * HD + 4 * fg
-            : q.kcache + (int64_t)q.tok_slot[m] * q.slot_stride + ((int64_t)(head - q.nH) * q.Tmax + pos) * HD + 4 * fg;
+            : q.kcache + (int64_t)blk * q.slot_stride + ((int64_t)(head - q.nH) * q.Tmax + row) * HD + 4 * fg;
 #pragma unroll
         for (int j = 0; j < TH; j++) {
             bf16x4 o;
@@ -169,7 +172,7 @@ __device__ __forceinline__ void epilogue_qkv_head(const GemmArgs& p, int m, int 
         }
     } else {
         const int kvh = head - q.nH - q.nKV;
-        bf16_t* dst = q.vcache + (int64_t)q.tok_slot[m] * q.slot_stride + (int64_t)kvh * q.Tmax * HD + pos;
+        bf16_t* dst = q.vcache + (int64_t)blk * q.slot_stride + (int64_t)kvh * q.Tmax * HD + row;
 #pragma unroll
         for (int j = 0; j < TH; j++)
 #pragma unroll

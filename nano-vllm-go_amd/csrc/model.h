@@ -71,7 +71,8 @@ struct nvl_model {
     void* tp_comm = nullptr;          // ncclComm_t
     nvl_local_group* tp_local = nullptr;   // in-process emulation (tests on one GPU)
     float* tp_part = nullptr;         // [Mmax][H] fp32 partial of a row-parallel projection
-    int n_qkv = 0, Tmax = 0;
+    int n_qkv = 0, Tmax = 0;     // Tmax: tokens per KV block (slab mode: the whole slot; paged: kv_block_size)
+    int paged = 0, num_blocks = 0, blocks_per_seq = 1, table_cap = 0;   // KV addressing (see kv_locate)
     float attn_scale = 0.f, resid_alpha = 1.f;
     size_t wsize = 2;            // bytes per weight/activation element
 

@@ -191,13 +191,22 @@ extern "C" int nvl_create(const nvl_model_config* cfg, const nvl_runtime_opts* o
     // columns; from here on nH / nKV / F are the LOCAL sizes (hidden H, vocab V stay full: residual stream,
     // norms, embeddings and the LM head are replicated)
     m->tp = tp; m->tp_rank = tp > 1 ? opts->tp_rank : 0;
-    m->tp_force = tp == 1 && opts->reserved[0] == 1;   // diagnostics: run the row-parallel path + all-reduce with one rank
+    m->tp_force = tp == 1 && opts->tp_force_single == 1;   // diagnostics: run the row-parallel path + all-reduce with one rank
     m->nH_full = m->nH; m->nKV_full = m->nKV; m->F_full = m->F;
     m->nH /= tp; m->nKV /= tp; m->F /= tp;
     m->group = m->nH / m->nKV;
     m->Vpad = (int)round_up(m->V, 128);
     m->n_qkv = (m->nH + 2 * m->nKV) * m->hd;
     m->Tmax = (int)round_up(c.max_seq_len, 64);
+    if (opts->kv_num_blocks > 0) {            // paged KV: the host's block manager names the blocks
+        const int bs = opts->kv_block_size > 0 ? opts->kv_block_size : 256;
+        if (bs % 64 != 0) throw std::runtime_error("kv_block_size must be a multiple of 64");
+        m->paged = 1; m->Tmax = bs; m->num_blocks = opts->kv_num_blocks;
+        m->blocks_per_seq = cdiv(c.max_seq_len, bs);
+    } else {
+        m->num_blocks = opts->max_seqs;
+    }
+    m->table_cap = opts->max_seqs * m->blocks_per_seq;
     // score scale: GQA uses AttentionMultiplier when set (attention.go:361-364); MHA/MQA 1/sqrt(hd)
     if (c.attention_type == NVL_ATTN_GQA && c.attention_multiplier != 0.f) m->attn_scale = c.attention_multiplier;
     else m->attn_scale = 1.0f / std::sqrt((float)m->hd);
@@ -593,7 +602,7 @@ extern "C" int nvl_finalize(nvl_model* m) {
     // ---- KV slabs: [slot][layer][kv head][Tmax][hd]; zero-filled so stale tiles hold finite values
     m->layer_stride = (int64_t)m->nKV * m->Tmax * hd;
     m->slot_stride = m->layer_stride * m->L;
-    const int64_t kv_elems = m->slot_stride * m->opts.max_seqs;
+    const int64_t kv_elems = m->slot_stride * m->num_blocks;
     m->kcache = dmalloc_bytes(kv_elems * (int64_t)m->wsize);
     m->vcache = dmalloc_bytes(kv_elems * (int64_t)m->wsize);
     NVL_HIP(hipMemsetAsync(m->kcache, 0, (size_t)kv_elems * m->wsize, m->stream));
@@ -639,7 +648,7 @@ extern "C" int nvl_finalize(nvl_model* m) {
     }
     if (!m->f32) m->sk_part = dmalloc<float>((int64_t)m->sk_max_slices * 64 * H);
     if (m->tp > 1 || m->tp_force) m->tp_part = dmalloc<float>(Mmax * H);
-    m->meta_ints = 3 * Mmax + 5 * S + 16;
+    m->meta_ints = 3 * Mmax + 5 * S + m->table_cap + 16;
     NVL_HIP(hipHostMalloc((void**)&m->meta_host, (size_t)m->meta_ints * 4, hipHostMallocDefault));
     m->meta_dev = dmalloc<int32_t>(m->meta_ints);
     NVL_HIP(hipStreamSynchronize(m->stream));   // every memset/copy above ran on the model's own (non-blocking) stream
@@ -703,6 +712,7 @@ extern "C" int nvl_tp_attach_local(nvl_model** models, int n) {
 // =================================================================================================
 extern "C" int nvl_seq_open(nvl_model* m, int64_t seq_id) {
     if (!m || !m->finalized) return fail(m, NVL_ERR_STATE, "nvl_seq_open: model not finalized");
+    if (m->paged) return fail(m, NVL_ERR_STATE, "nvl_seq_open: the model is in paged-KV mode (the host's block manager owns the cache)");
     if (m->seq_slot.count(seq_id)) return NVL_OK;
     if (m->free_slots.empty()) return fail(m, NVL_ERR_NO_SLOT, "nvl_seq_open: all KV slots in use");
     const int s = m->free_slots.back(); m->free_slots.pop_back();
@@ -742,8 +752,19 @@ extern "C" int nvl_seq_len(nvl_model* m, int64_t seq_id) {
 namespace {
 
 struct Meta {   // device pointers into meta_dev
-    int32_t *tokens, *tok_pos, *tok_slot, *seq_tok_start, *seq_len, *seq_pos, *seq_slot, *last_rows;
+    int32_t *tokens, *tok_pos, *tok_tbl, *seq_tok_start, *seq_len, *seq_pos, *seq_tbl, *last_rows, *blk_table;
 };
+// layout of meta_host / meta_dev for a call carrying M tokens:
+//   [seq_tok_start S | seq_len S | seq_pos S | seq_tbl S | last_rows S | blk_table table_cap | tokens M | tok_pos M | tok_tbl M]
+Meta bind_meta(const nvl_model* m, int32_t* base, int M) {
+    const int64_t S = m->opts.max_seqs;
+    Meta md;
+    md.seq_tok_start = base; md.seq_len = base + S; md.seq_pos = base + 2 * S; md.seq_tbl = base + 3 * S;
+    md.last_rows = base + 4 * S; md.blk_table = base + 5 * S;
+    md.tokens = md.blk_table + m->table_cap; md.tok_pos = md.tokens + M; md.tok_tbl = md.tok_pos + M;
+    return md;
+}
+size_t meta_bytes(const nvl_model* m, int M) { return (size_t)(5 * (int64_t)m->opts.max_seqs + m->table_cap + 3 * (int64_t)M) * 4; }
 
 template <typename ActT>
 void launch_norm(nvl_model* m, float* x, const int32_t* rows_idx, const float* w, const float* b,
@@ -775,7 +796,8 @@ void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, do
     a.kcache = (char*)m->kcache + (size_t)li * m->layer_stride * m->wsize;
     a.vcache = (char*)m->vcache + (size_t)li * m->layer_stride * m->wsize;
     a.slot_stride = m->slot_stride; a.Tmax = m->Tmax;
-    a.seq_tok_start = md.seq_tok_start; a.seq_len = md.seq_len; a.seq_pos = md.seq_pos; a.seq_slot = md.seq_slot;
+    a.seq_tok_start = md.seq_tok_start; a.seq_len = md.seq_len; a.seq_pos = md.seq_pos; a.blk_table = md.blk_table; a.tbl_stride = m->blocks_per_seq;
+    a.bs_shift = (m->Tmax & (m->Tmax - 1)) == 0 ? __builtin_ctz((unsigned)m->Tmax) : -1;
     a.nH = m->nH; a.nKV = m->nKV; a.group = m->group; a.scale = m->attn_scale;
     KScope ks(m, KC_ATTN, flops);
     if (m->f32) {
@@ -808,11 +830,11 @@ void rope_kv(nvl_model* m, int li, const Meta& md, int M) {
     void* vc = (char*)m->vcache + (size_t)li * m->layer_stride * m->wsize;
     if (m->f32)
         hipLaunchKernelGGL((rope_kv_kernel<float, false>), grid, dim3(thr), 0, m->stream, m->qkv, m->n_qkv,
-                           md.tok_pos, md.tok_slot, m->rope_cos, m->rope_sin, (float*)m->q, m->nH * m->hd,
+                           md.tok_pos, md.tok_tbl, md.blk_table, m->rope_cos, m->rope_sin, (float*)m->q, m->nH * m->hd,
                            (float*)kc, (float*)vc, m->slot_stride, m->Tmax, m->nH, m->nKV, m->hd);
     else
         hipLaunchKernelGGL((rope_kv_kernel<bf16_t, true>), grid, dim3(thr), 0, m->stream, m->qkv, m->n_qkv,
-                           md.tok_pos, md.tok_slot, m->rope_cos, m->rope_sin, (bf16_t*)m->q, m->nH * m->hd,
+                           md.tok_pos, md.tok_tbl, md.blk_table, m->rope_cos, m->rope_sin, (bf16_t*)m->q, m->nH * m->hd,
                            (bf16_t*)kc, (bf16_t*)vc, m->slot_stride, m->Tmax, m->nH, m->nKV, m->hd);
     NVL_HIP(hipGetLastError());
 }
@@ -1024,7 +1046,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
         if (!m->f32 && M > 64) {
             // prefill: RoPE + Q/K/V placement fused into the projection's epilogue (no fp32 qkv round trip)
             GemmArgs a = mk(m->xn, H, l.w_qkv, nullptr, 0, l.b_qkv, 1.f, M, m->n_qkv, H);
-            a.qkv.tok_pos = md.tok_pos; a.qkv.tok_slot = md.tok_slot; a.qkv.cos_t = m->rope_cos; a.qkv.sin_t = m->rope_sin;
+            a.qkv.tok_pos = md.tok_pos; a.qkv.tok_tbl = md.tok_tbl; a.qkv.blk_table = md.blk_table; a.qkv.cos_t = m->rope_cos; a.qkv.sin_t = m->rope_sin;
             a.qkv.q_out = (bf16_t*)m->q;
             a.qkv.kcache = (bf16_t*)m->kcache + (int64_t)li * m->layer_stride;
             a.qkv.vcache = (bf16_t*)m->vcache + (int64_t)li * m->layer_stride;
@@ -1117,11 +1139,11 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
     }
     if (M64 > m->opts.max_batch_tokens) return fail(m, NVL_ERR_INVALID, "nvl_forward: batch exceeds max_batch_tokens");
     const int M = (int)M64;
-    int32_t* h = m->meta_host;
-    const int64_t Mmax = m->opts.max_batch_tokens, S = m->opts.max_seqs;
-    (void)Mmax;
-    int32_t *h_sts = h, *h_len = h_sts + S, *h_pos = h_len + S, *h_slot = h_pos + S, *h_last = h_slot + S,
-            *h_tokens = h + 5 * S, *h_tok_pos = h_tokens + M, *h_tok_slot = h_tok_pos + M;
+    if (m->paged) return fail(m, NVL_ERR_STATE, "nvl_forward: the model is in paged-KV mode (use nvl_forward_paged)");
+    const Meta hm = bind_meta(m, m->meta_host, M);
+    int32_t *h_sts = hm.seq_tok_start, *h_len = hm.seq_len, *h_pos = hm.seq_pos, *h_tbl = hm.seq_tbl, *h_last = hm.last_rows,
+            *h_tokens = hm.tokens, *h_tok_pos = hm.tok_pos, *h_tok_tbl = hm.tok_tbl;
+    std::vector<int> h_slot((size_t)n_seqs);
     int t = 0;
     for (int i = 0; i < n_seqs; i++) {
         auto it = m->seq_slot.find(seq_ids[i]);
@@ -1131,20 +1153,18 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
         if (pos_offsets[i] != m->slot_len[(size_t)slot]) return fail(m, NVL_ERR_INVALID, "nvl_forward: pos_offset does not equal the cached length");
         if (pos_offsets[i] + seq_lens[i] > c.max_seq_len)   // rope.go:84-86 / :176-178 panic
             return fail(m, NVL_ERR_POSITION, "nvl_forward: position exceeds max_seq_len");
-        h_sts[i] = t; h_len[i] = seq_lens[i]; h_pos[i] = pos_offsets[i]; h_slot[i] = slot;
+        // slab mode: the sequence's block table is the one entry blk_table[i] = its slot
+        h_sts[i] = t; h_len[i] = seq_lens[i]; h_pos[i] = pos_offsets[i]; h_slot[(size_t)i] = slot; h_tbl[i] = i; hm.blk_table[i] = slot;     // (blocks_per_seq == 1 here)
         for (int j = 0; j < seq_lens[i]; j++, t++) {
             const int tok = tokens[t];
             if (tok < 0 || tok >= m->V) return fail(m, NVL_ERR_INVALID, "nvl_forward: token id out of range");
-            h_tokens[t] = tok; h_tok_pos[t] = pos_offsets[i] + j; h_tok_slot[t] = slot;
+            h_tokens[t] = tok; h_tok_pos[t] = pos_offsets[i] + j; h_tok_tbl[t] = i;
         }
         h_last[i] = t - 1;
     }
-    Meta md;
-    md.seq_tok_start = m->meta_dev; md.seq_len = md.seq_tok_start + S; md.seq_pos = md.seq_len + S;
-    md.seq_slot = md.seq_pos + S; md.last_rows = md.seq_slot + S;
-    md.tokens = m->meta_dev + 5 * S; md.tok_pos = md.tokens + M; md.tok_slot = md.tok_pos + M;
+    const Meta md = bind_meta(m, m->meta_dev, M);
     NVL_HIP(hipEventRecord(m->ev0, m->stream));
-    NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, (size_t)(5 * S + 3 * (int64_t)M) * 4, hipMemcpyHostToDevice, m->stream));
+    NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, meta_bytes(m, M), hipMemcpyHostToDevice, m->stream));
 
     double attn_flops = 0;   // 4*hd per (query, visible key) pair per head
     for (int i = 0; i < n_seqs; i++) {
@@ -1164,7 +1184,7 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
         if (all) for (int i = 0; i < n_seqs; i++) argmax_out[i] = am[(size_t)h_last[i]];
         else for (int i = 0; i < n_seqs; i++) argmax_out[i] = am[(size_t)i];
     }
-    for (int i = 0; i < n_seqs; i++) m->slot_len[(size_t)h_slot[i]] += seq_lens[i];
+    for (int i = 0; i < n_seqs; i++) m->slot_len[(size_t)h_slot[(size_t)i]] += seq_lens[i];
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, m->ev0, m->ev1);
     m->stats.forward_calls++;
@@ -1173,6 +1193,136 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
     if (m->profile) drain_profile(m);
     return NVL_OK;
     NVL_CATCH(m)
+}
+
+// nvl_forward for a model whose KV cache is the host block manager's pool (block_manager.go:128-263,
+// sequence.go:22-23): no per-sequence state here, the block tables say where every position lives.
+extern "C" int nvl_forward_paged(nvl_model* m, int n_seqs, const int32_t* tokens, const int32_t* seq_lens,
+                                 const int32_t* pos_offsets, const int32_t* block_tables, const int32_t* table_offsets,
+                                 uint32_t flags, float* logits_out, int32_t* argmax_out) {
+    if (!m) return NVL_ERR_INVALID;
+    if (!m->finalized) return fail(m, NVL_ERR_STATE, "nvl_forward_paged: model not finalized");
+    if (!m->paged) return fail(m, NVL_ERR_STATE, "nvl_forward_paged: the model was created without kv_num_blocks");
+    if (n_seqs <= 0 || !tokens || !seq_lens || !pos_offsets || !block_tables || !table_offsets)
+        return fail(m, NVL_ERR_INVALID, "nvl_forward_paged: null/empty arguments");
+    if (n_seqs > m->opts.max_seqs) return fail(m, NVL_ERR_INVALID, "nvl_forward_paged: n_seqs exceeds max_seqs");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    const nvl_model_config& c = m->cfg;
+    const int BS = m->Tmax;
+    int64_t M64 = 0; int max_len = 0; bool prefill = false;
+    for (int i = 0; i < n_seqs; i++) {
+        if (seq_lens[i] <= 0) return fail(m, NVL_ERR_INVALID, "nvl_forward_paged: empty sequence");
+        if (pos_offsets[i] < 0) return fail(m, NVL_ERR_INVALID, "nvl_forward_paged: negative pos_offset");
+        M64 += seq_lens[i]; max_len = std::max(max_len, seq_lens[i]);
+        if (seq_lens[i] > 1) prefill = true;
+    }
+    if (M64 > m->opts.max_batch_tokens) return fail(m, NVL_ERR_INVALID, "nvl_forward_paged: batch exceeds max_batch_tokens");
+    const int M = (int)M64;
+    const Meta hm = bind_meta(m, m->meta_host, M);
+    int t = 0, tb = 0;
+    for (int i = 0; i < n_seqs; i++) {
+        const int end = pos_offsets[i] + seq_lens[i];
+        if (end > c.max_seq_len) return fail(m, NVL_ERR_POSITION, "nvl_forward_paged: position exceeds max_seq_len");
+        const int nb = table_offsets[i + 1] - table_offsets[i];
+        if (nb < cdiv(end, BS)) return fail(m, NVL_ERR_INVALID, "nvl_forward_paged: block table shorter than the sequence");
+        if (nb > m->blocks_per_seq) return fail(m, NVL_ERR_INVALID, "nvl_forward_paged: block table too long");
+        tb = i * m->blocks_per_seq;                      // fixed stride: the kernels index blk_table[seq][block]
+        hm.seq_tok_start[i] = t; hm.seq_len[i] = seq_lens[i]; hm.seq_pos[i] = pos_offsets[i]; hm.seq_tbl[i] = tb;
+        for (int j = 0; j < nb; j++) {
+            const int b = block_tables[table_offsets[i] + j];
+            if (b < 0 || b >= m->num_blocks) return fail(m, NVL_ERR_INVALID, "nvl_forward_paged: block id out of range");
+            hm.blk_table[tb + j] = b;
+        }
+        for (int j = 0; j < seq_lens[i]; j++, t++) {
+            const int tok = tokens[t];
+            if (tok < 0 || tok >= m->V) return fail(m, NVL_ERR_INVALID, "nvl_forward_paged: token id out of range");
+            hm.tokens[t] = tok; hm.tok_pos[t] = pos_offsets[i] + j; hm.tok_tbl[t] = tb;
+        }
+        hm.last_rows[i] = t - 1;
+    }
+    const Meta md = bind_meta(m, m->meta_dev, M);
+    NVL_HIP(hipEventRecord(m->ev0, m->stream));
+    NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, meta_bytes(m, M), hipMemcpyHostToDevice, m->stream));
+    double attn_flops = 0;
+    for (int i = 0; i < n_seqs; i++) {
+        const double s = seq_lens[i], p0 = pos_offsets[i];
+        attn_flops += 4.0 * m->hd * m->nH * (s * p0 + s * (s + 1) / 2);
+    }
+    const bool all = (flags & NVL_FWD_ALL_LOGITS) != 0;
+    const int rows = enqueue_forward(m, md, n_seqs, M, max_len, attn_flops, flags);
+    NVL_HIP(hipEventRecord(m->ev1, m->stream));
+    std::vector<int32_t> am((size_t)rows);
+    NVL_HIP(hipMemcpyAsync(am.data(), m->argmax_dev, (size_t)rows * 4, hipMemcpyDeviceToHost, m->stream));
+    if (logits_out)
+        NVL_HIP(hipMemcpy2DAsync(logits_out, (size_t)m->V * 4, m->logits, (size_t)m->Vpad * 4, (size_t)m->V * 4,
+                                 (size_t)rows, hipMemcpyDeviceToHost, m->stream));
+    NVL_HIP(hipStreamSynchronize(m->stream));
+    if (argmax_out) {
+        if (all) for (int i = 0; i < n_seqs; i++) argmax_out[i] = am[(size_t)hm.last_rows[i]];
+        else for (int i = 0; i < n_seqs; i++) argmax_out[i] = am[(size_t)i];
+    }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, m->ev0, m->ev1);
+    m->stats.forward_calls++;
+    if (prefill) { m->stats.prefill_tokens += (uint64_t)M; m->stats.prefill_ms += ms; }
+    else { m->stats.decode_tokens += (uint64_t)M; m->stats.decode_ms += ms; }
+    if (m->profile) drain_profile(m);
+    return NVL_OK;
+    NVL_CATCH(m)
+}
+
+// ModelRunner.Run over block tables: what a runner that honours Sequence.BlockTable / NumCachedTokens does
+// (the reference's runners ignore both: SURVEY §2 row 17).
+extern "C" int nvl_runner_run_paged(nvl_model* m, int n_seqs, const int32_t* const* token_ptrs, const int32_t* token_lens,
+                                    const int32_t* num_cached_tokens, const int32_t* const* block_table_ptrs,
+                                    const int32_t* block_table_lens, int is_prefill, int32_t* next_tokens,
+                                    float* logits_out) {
+    if (!m) return NVL_ERR_INVALID;
+    if (!m->paged) return fail(m, NVL_ERR_STATE, "nvl_runner_run_paged: the model was created without kv_num_blocks");
+    if (n_seqs <= 0 || !token_ptrs || !token_lens || !block_table_ptrs || !block_table_lens || !next_tokens)
+        return fail(m, NVL_ERR_INVALID, "nvl_runner_run_paged: null/empty arguments");
+    const int V = m->V;
+    int k = 0;
+    while (k < n_seqs) {
+        // pack sequences into one forward call while they fit max_seqs / max_batch_tokens
+        std::vector<int32_t> toks, lens, pos, tbl, off{0};
+        std::vector<int> who;
+        int64_t budget = m->opts.max_batch_tokens;
+        while (k < n_seqs && (int)who.size() < m->opts.max_seqs) {
+            const int len = token_lens[k];
+            if (len <= 0) return fail(m, NVL_ERR_INVALID, "nvl_runner_run_paged: sequence without tokens");
+            int p0;
+            if (is_prefill) {
+                p0 = num_cached_tokens ? num_cached_tokens[k] : 0;
+                if (p0 < 0 || p0 > len) return fail(m, NVL_ERR_INVALID, "nvl_runner_run_paged: num_cached_tokens outside [0, len]");
+                if (p0 == len) p0 = len - 1;                 // whole prompt cached: the last token still has to produce logits
+            } else {
+                p0 = len - 1;                                // tensor_model_runner.go:78-80
+            }
+            const int n_new = len - p0;
+            if (n_new > m->opts.max_batch_tokens) return fail(m, NVL_ERR_INVALID, "nvl_runner_run_paged: uncached suffix exceeds max_batch_tokens");
+            if (n_new > budget) break;
+            toks.insert(toks.end(), token_ptrs[k] + p0, token_ptrs[k] + len);
+            lens.push_back(n_new); pos.push_back(p0);
+            if (block_table_lens[k] < 0) return fail(m, NVL_ERR_INVALID, "nvl_runner_run_paged: negative block table length");
+            tbl.insert(tbl.end(), block_table_ptrs[k], block_table_ptrs[k] + block_table_lens[k]);
+            off.push_back((int32_t)tbl.size());
+            who.push_back(k);
+            budget -= n_new;
+            k++;
+        }
+        std::vector<int32_t> out(who.size());
+        std::vector<float> lg(logits_out ? who.size() * (size_t)V : 0);
+        const int rc = nvl_forward_paged(m, (int)who.size(), toks.data(), lens.data(), pos.data(), tbl.data(), off.data(), 0,
+                                         logits_out ? lg.data() : nullptr, out.data());
+        if (rc) return rc;
+        for (size_t j = 0; j < who.size(); j++) {
+            next_tokens[who[j]] = out[j];
+            if (logits_out) memcpy(logits_out + (size_t)who[j] * V, &lg[j * (size_t)V], (size_t)V * 4);
+        }
+    }
+    return NVL_OK;
 }
 
 // The greedy decode loop of cmd/ask (main.go:315-360, without the EOS stop) as ONE call: `n_steps` forward passes of one
@@ -1188,11 +1338,12 @@ extern "C" int nvl_decode_greedy(nvl_model* m, int n_seqs, const int64_t* seq_id
         return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy: n_seqs exceeds max_seqs / max_batch_tokens");
     NVL_TRY(m)
     NVL_HIP(hipSetDevice(m->device));
-    const int64_t S = m->opts.max_seqs;
+    if (m->paged) return fail(m, NVL_ERR_STATE, "nvl_decode_greedy: not available in paged-KV mode");
     const int M = n_seqs;
-    int32_t* h = m->meta_host;
-    int32_t *h_sts = h, *h_len = h_sts + S, *h_pos = h_len + S, *h_slot = h_pos + S, *h_last = h_slot + S,
-            *h_tokens = h + 5 * S, *h_tok_pos = h_tokens + M, *h_tok_slot = h_tok_pos + M;
+    const Meta hm = bind_meta(m, m->meta_host, M);
+    int32_t *h_sts = hm.seq_tok_start, *h_len = hm.seq_len, *h_pos = hm.seq_pos, *h_tbl = hm.seq_tbl, *h_last = hm.last_rows,
+            *h_tokens = hm.tokens, *h_tok_pos = hm.tok_pos, *h_tok_tbl = hm.tok_tbl;
+    std::vector<int> h_slot((size_t)n_seqs);
     for (int i = 0; i < n_seqs; i++) {
         auto it = m->seq_slot.find(seq_ids[i]);
         if (it == m->seq_slot.end()) return fail(m, NVL_ERR_UNKNOWN_SEQ, "nvl_decode_greedy: sequence has no KV slot");
@@ -1200,20 +1351,17 @@ extern "C" int nvl_decode_greedy(nvl_model* m, int n_seqs, const int64_t* seq_id
         const int slot = it->second, pos = m->slot_len[(size_t)slot];
         if (pos + n_steps > m->cfg.max_seq_len) return fail(m, NVL_ERR_POSITION, "nvl_decode_greedy: position exceeds max_seq_len");
         if (first_tokens[i] < 0 || first_tokens[i] >= m->V) return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy: token id out of range");
-        h_sts[i] = i; h_len[i] = 1; h_pos[i] = pos; h_slot[i] = slot; h_last[i] = i;
-        h_tokens[i] = first_tokens[i]; h_tok_pos[i] = pos; h_tok_slot[i] = slot;
+        h_sts[i] = i; h_len[i] = 1; h_pos[i] = pos; h_slot[(size_t)i] = slot; h_last[i] = i; h_tbl[i] = i; hm.blk_table[i] = slot;
+        h_tokens[i] = first_tokens[i]; h_tok_pos[i] = pos; h_tok_tbl[i] = i;
     }
-    Meta md;
-    md.seq_tok_start = m->meta_dev; md.seq_len = md.seq_tok_start + S; md.seq_pos = md.seq_len + S;
-    md.seq_slot = md.seq_pos + S; md.last_rows = md.seq_slot + S;
-    md.tokens = m->meta_dev + 5 * S; md.tok_pos = md.tokens + M; md.tok_slot = md.tok_pos + M;
+    const Meta md = bind_meta(m, m->meta_dev, M);
     if ((int64_t)n_steps * n_seqs > m->ring_ints) {
         dfree(m->ring);
         m->ring_ints = (int64_t)n_steps * n_seqs;
         m->ring = dmalloc<int32_t>(m->ring_ints);
     }
     NVL_HIP(hipEventRecord(m->ev0, m->stream));
-    NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, (size_t)(5 * S + 3 * (int64_t)M) * 4, hipMemcpyHostToDevice, m->stream));
+    NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, meta_bytes(m, M), hipMemcpyHostToDevice, m->stream));
     const bool dbg = m->keep_hidden;
     m->keep_hidden = false;                      // the per-layer taps belong to single nvl_forward calls
     for (int s = 0; s < n_steps; s++) {
@@ -1228,7 +1376,7 @@ extern "C" int nvl_decode_greedy(nvl_model* m, int n_seqs, const int64_t* seq_id
     NVL_HIP(hipEventRecord(m->ev1, m->stream));
     NVL_HIP(hipMemcpyAsync(out_tokens, m->ring, (size_t)n_steps * n_seqs * 4, hipMemcpyDeviceToHost, m->stream));
     NVL_HIP(hipStreamSynchronize(m->stream));
-    for (int i = 0; i < n_seqs; i++) m->slot_len[(size_t)h_slot[i]] += n_steps;
+    for (int i = 0; i < n_seqs; i++) m->slot_len[(size_t)h_slot[(size_t)i]] += n_steps;
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, m->ev0, m->ev1);
     m->stats.forward_calls += (uint64_t)n_steps;
@@ -1257,32 +1405,61 @@ extern "C" int nvl_get_hidden(nvl_model* m, int layer, float* out, int64_t n_flo
     NVL_CATCH(m)
 }
 
+namespace {
+// K and V of positions 0..T-1 of one block list, laid out as the reference does ([nKV, T, hd] fp32, kv_cache.go:5-6)
+void read_kv(nvl_model* m, const int32_t* blocks, int n_blocks, int T, int layer, float* k_out, float* v_out) {
+    const int hd = m->hd, BS = m->Tmax;
+    const int64_t n = m->layer_stride;
+    std::vector<char> kb((size_t)n * m->wsize), vb((size_t)n * m->wsize);
+    auto rd = [&](const std::vector<char>& b, int64_t i) -> float {
+        if (m->f32) return ((const float*)b.data())[i];
+        uint32_t u = ((uint32_t)((const uint16_t*)b.data())[i]) << 16;
+        float f; memcpy(&f, &u, 4); return f;
+    };
+    for (int bi = 0; bi < n_blocks && bi * BS < T; bi++) {
+        const size_t off = ((size_t)blocks[bi] * m->slot_stride + (size_t)layer * m->layer_stride) * m->wsize;
+        NVL_HIP(hipMemcpy(kb.data(), (char*)m->kcache + off, kb.size(), hipMemcpyDeviceToHost));
+        NVL_HIP(hipMemcpy(vb.data(), (char*)m->vcache + off, vb.size(), hipMemcpyDeviceToHost));
+        const int t1 = std::min(T, (bi + 1) * BS);
+        for (int h = 0; h < m->nKV; h++)
+            for (int t = bi * BS; t < t1; t++)
+                for (int d = 0; d < hd; d++) {
+                    const int r = t - bi * BS;
+                    const int64_t o = ((int64_t)h * T + t) * hd + d;
+                    if (k_out) k_out[o] = rd(kb, ((int64_t)h * BS + r) * hd + d);
+                    if (v_out) v_out[o] = m->f32 ? rd(vb, ((int64_t)h * BS + r) * hd + d)
+                                                 : rd(vb, ((int64_t)h * hd + d) * BS + r);   // bf16 path keeps V^T
+                }
+    }
+}
+}  // namespace
+
 extern "C" int nvl_get_kv(nvl_model* m, int64_t seq_id, int layer, float* k_out, float* v_out) {
     if (!m) return NVL_ERR_INVALID;
     auto it = m->seq_slot.find(seq_id);
     if (it == m->seq_slot.end()) return fail(m, NVL_ERR_UNKNOWN_SEQ, "nvl_get_kv: unknown sequence");
     if (layer < 0 || layer >= m->L) return fail(m, NVL_ERR_INVALID, "nvl_get_kv: bad layer");
     NVL_TRY(m)
-    const int slot = it->second, T = m->slot_len[(size_t)slot], hd = m->hd, Tmax = m->Tmax;
-    const int64_t n = m->layer_stride;
-    const size_t off = ((size_t)slot * m->slot_stride + (size_t)layer * m->layer_stride) * m->wsize;
-    std::vector<char> kb((size_t)n * m->wsize), vb((size_t)n * m->wsize);
-    NVL_HIP(hipMemcpy(kb.data(), (char*)m->kcache + off, kb.size(), hipMemcpyDeviceToHost));
-    NVL_HIP(hipMemcpy(vb.data(), (char*)m->vcache + off, vb.size(), hipMemcpyDeviceToHost));
-    auto rd = [&](const std::vector<char>& b, int64_t i) -> float {
-        if (m->f32) return ((const float*)b.data())[i];
-        uint32_t u = ((uint32_t)((const uint16_t*)b.data())[i]) << 16;
-        float f; memcpy(&f, &u, 4); return f;
-    };
-    for (int h = 0; h < m->nKV; h++)
-        for (int t = 0; t < T; t++)
-            for (int d = 0; d < hd; d++) {
-                const int64_t o = ((int64_t)h * T + t) * hd + d;
-                if (k_out) k_out[o] = rd(kb, ((int64_t)h * Tmax + t) * hd + d);
-                if (v_out) v_out[o] = m->f32 ? rd(vb, ((int64_t)h * Tmax + t) * hd + d)
-                                             : rd(vb, ((int64_t)h * hd + d) * Tmax + t);   // bf16 path keeps V^T
-            }
+    NVL_HIP(hipSetDevice(m->device));
+    const int32_t slot = it->second;
+    const int T = m->slot_len[(size_t)slot];
+    read_kv(m, &slot, 1, T, layer, k_out, v_out);
     return T;
+    NVL_CATCH(m)
+}
+
+extern "C" int nvl_get_kv_paged(nvl_model* m, const int32_t* block_table, int n_blocks, int n_tokens, int layer,
+                                float* k_out, float* v_out) {
+    if (!m) return NVL_ERR_INVALID;
+    if (!m->paged) return fail(m, NVL_ERR_STATE, "nvl_get_kv_paged: the model is not in paged-KV mode");
+    if (!block_table || n_blocks <= 0 || n_tokens < 0 || n_tokens > n_blocks * m->Tmax || layer < 0 || layer >= m->L)
+        return fail(m, NVL_ERR_INVALID, "nvl_get_kv_paged: bad arguments");
+    for (int i = 0; i < n_blocks; i++)
+        if (block_table[i] < 0 || block_table[i] >= m->num_blocks) return fail(m, NVL_ERR_INVALID, "nvl_get_kv_paged: block id out of range");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    read_kv(m, block_table, n_blocks, n_tokens, layer, k_out, v_out);
+    return n_tokens;
     NVL_CATCH(m)
 }
 

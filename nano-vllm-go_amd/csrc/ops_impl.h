@@ -156,7 +156,7 @@ extern "C" int nvl_op_rope(int device, float* t, int heads, int seq, int hd, int
     NVL_HIP(hipMemcpyAsync(dpos, pos.data(), (size_t)seq * 4, hipMemcpyHostToDevice, cx.m.stream));
     NVL_HIP(hipMemcpyAsync(dslot, slot.data(), (size_t)seq * 4, hipMemcpyHostToDevice, cx.m.stream));
     float* dout = (float*)cx.alloc((int64_t)tm.size() * 4);
-    hipLaunchKernelGGL((rope_kv_kernel<float, false>), dim3(seq, heads), dim3(half), 0, cx.m.stream, dq, heads * hd, dpos, dslot,
+    hipLaunchKernelGGL((rope_kv_kernel<float, false>), dim3(seq, heads), dim3(half), 0, cx.m.stream, dq, heads * hd, dpos, dslot, dslot,
                        dc, ds, dout, heads * hd, (float*)nullptr, (float*)nullptr, (int64_t)0, max_seq, heads, 0, hd);
     NVL_HIP(hipGetLastError());
     cx.down(tm.data(), dout, (int64_t)tm.size());
@@ -195,11 +195,12 @@ extern "C" int nvl_op_attention(int device, int precision, const float* q, const
     m.nH = nH; m.nKV = nKV; m.group = nH / nKV; m.hd = hd; m.Tmax = Tmax; m.L = 1;
     m.layer_stride = (int64_t)nKV * Tmax * hd; m.slot_stride = m.layer_stride;
     m.attn_scale = scale != 0.f ? scale : 1.0f / std::sqrt((float)hd);
-    const int32_t meta[4] = {0, S, T - S, 0};
-    int32_t* dmeta = (int32_t*)cx.alloc(16);
-    NVL_HIP(hipMemcpyAsync(dmeta, meta, 16, hipMemcpyHostToDevice, m.stream));
+    const int32_t meta[5] = {0, S, T - S, 0, 0};      // one sequence whose block table is the single block 0
+    int32_t* dmeta = (int32_t*)cx.alloc(20);
+    NVL_HIP(hipMemcpyAsync(dmeta, meta, 20, hipMemcpyHostToDevice, m.stream));
     Meta md{};
-    md.seq_tok_start = dmeta; md.seq_len = dmeta + 1; md.seq_pos = dmeta + 2; md.seq_slot = dmeta + 3;
+    md.seq_tok_start = dmeta; md.seq_len = dmeta + 1; md.seq_pos = dmeta + 2; md.seq_tbl = dmeta + 3; md.blk_table = dmeta + 4;
+    m.blocks_per_seq = 1;
     attention(&m, 0, md, 1, S, 0.0);
     // back to fp32 [nH, S, hd]
     std::vector<float> ot((size_t)S * nH * hd);

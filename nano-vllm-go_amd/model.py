@@ -40,7 +40,7 @@ class HipTransformerModel:
 
     def __init__(self, cfg: dict, tensors: dict | None, *, device: int = 0, precision: str = "bf16",
                  max_seqs: int = 8, max_batch_tokens: int | None = None, tp_rank: int = 0, tp_size: int = 1,
-                 tp_force_single: bool = False):
+                 tp_force_single: bool = False, kv_num_blocks: int = 0, kv_block_size: int = 0):
         """tensors=None defers finalize(): upload() each tensor, then call finalize().
         tp_size > 1 makes this the tp_rank-th tensor-parallel shard: pass the FULL tensors, the library keeps
         its slice; join the shards with tp_init (RCCL, one process per GPU) or attach_local_group (tests)."""
@@ -50,7 +50,10 @@ class HipTransformerModel:
         opts = L.RuntimeOptsC(device=device, precision=L.PRECISION[precision], max_seqs=max_seqs,
                               max_batch_tokens=max_batch_tokens or cfg["max_seq_len"], tp_rank=tp_rank, tp_size=tp_size)
         if tp_force_single:
-            opts.reserved[0] = 1
+            opts.tp_force_single = 1
+        # kv_num_blocks > 0: paged KV — the host's block manager (nanovllm/block_manager.go) owns the cache
+        opts.kv_num_blocks, opts.kv_block_size = int(kv_num_blocks), int(kv_block_size)
+        self.kv_block_size = (kv_block_size or 256) if kv_num_blocks else 0
         self._c = _cfg_struct(cfg)
         L.check(self.lib.nvl_create(C.byref(self._c), C.byref(opts), C.byref(self.h)))
         self.V = cfg["vocab_size"]
@@ -144,6 +147,31 @@ class HipTransformerModel:
             out.append(int(am[0]))
             all_tokens.append(out[-1])
         return out
+
+    def forward_paged(self, token_lists, pos_offsets, block_tables, *, all_logits=False, want_logits=True):
+        """nvl_forward_paged: new tokens of each sequence at pos_offsets, KV through the sequences' block tables
+        (Sequence.BlockTable).  Returns (logits [rows, V] or None, argmax [n_seqs])."""
+        n = len(token_lists)
+        lens = np.asarray([len(t) for t in token_lists], np.int32)
+        toks = np.concatenate([np.asarray(t, np.int32) for t in token_lists]).astype(np.int32)
+        pos = np.asarray(pos_offsets, np.int32)
+        tbl = np.concatenate([np.asarray(b, np.int32) for b in block_tables]).astype(np.int32)
+        off = np.concatenate([[0], np.cumsum([len(b) for b in block_tables])]).astype(np.int32)
+        rows = int(lens.sum()) if all_logits else n
+        logits = np.empty((rows, self.V), np.float32) if want_logits else None
+        am = np.empty(n, np.int32)
+        L.check(self.lib.nvl_forward_paged(self.h, n, _ptr(toks), _ptr(lens), _ptr(pos), _ptr(tbl), _ptr(off),
+                                           L.FWD_ALL_LOGITS if all_logits else 0, _ptr(logits), _ptr(am)), self.h)
+        return logits, am
+
+    def get_kv_paged(self, block_table, n_tokens: int, layer: int):
+        tbl = np.ascontiguousarray(block_table, dtype=np.int32)
+        nkv = self.cfg["num_heads"] if self.cfg["attention_type"] == "mha" else (
+            1 if self.cfg["attention_type"] == "mqa" else self.cfg["num_kv_heads"])
+        k = np.empty((nkv, n_tokens, self.cfg["head_dim"]), np.float32)
+        v = np.empty_like(k)
+        L.check(self.lib.nvl_get_kv_paged(self.h, _ptr(tbl), tbl.size, n_tokens, layer, _ptr(k), _ptr(v)), self.h)
+        return k, v
 
     def decode_greedy(self, seq_ids, first_tokens, n_steps: int):
         """nvl_decode_greedy: n_steps greedy decode steps with the token feedback on the device -> [n_steps, n_seqs]."""

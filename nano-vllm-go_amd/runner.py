@@ -20,6 +20,9 @@ class Sequence:
     seq_id: int
     token_ids: list = field(default_factory=list)
     temperature: float = 1.0
+    num_cached_tokens: int = 0                     # sequence.go:22, set by BlockManager.Allocate on a prefix-cache hit
+    block_table: list = field(default_factory=list)   # sequence.go:23
+    block_size: int = 256                          # sequence.go:51
 
     def append_token(self, tok: int):          # sequence.go AppendToken
         self.token_ids.append(int(tok))
@@ -92,4 +95,39 @@ class HipModelRunner:
 
     def close(self):                                                           # :114-117
         self.clear_all_caches()
+        return None
+
+
+class HipPagedModelRunner:
+    """A ModelRunner that honours what the scheduler's BlockManager computed (block_manager.go:128-263) — the
+    reference's runners ignore Sequence.BlockTable / NumCachedTokens.  The model must be created with
+    kv_num_blocks = the block manager's pool size; the KV cache then IS that pool: prefix-cache hits skip their
+    prefill work, finished sequences free memory the moment the block manager reuses their blocks."""
+
+    def __init__(self, model: HipTransformerModel):
+        self.model = model
+        self.lib = model.lib
+
+    def run(self, seqs, is_prefill: bool, return_logits: bool = False):
+        n = len(seqs)
+        if n == 0:
+            return ([], None) if return_logits else []
+        arrs = [np.ascontiguousarray(s.token_ids, dtype=np.int32) for s in seqs]
+        tbls = [np.ascontiguousarray(s.block_table, dtype=np.int32) for s in seqs]
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data_as(C.c_void_p).value for a in arrs])
+        tptrs = (C.c_void_p * n)(*[a.ctypes.data_as(C.c_void_p).value for a in tbls])
+        lens = np.asarray([a.size for a in arrs], np.int32)
+        tlens = np.asarray([a.size for a in tbls], np.int32)
+        cached = np.asarray([s.num_cached_tokens for s in seqs], np.int32)
+        out = np.empty(n, np.int32)
+        logits = np.empty((n, self.model.V), np.float32) if return_logits else None
+        L.check(self.lib.nvl_runner_run_paged(self.model.h, n, ptrs, lens.ctypes.data_as(C.c_void_p),
+                                              cached.ctypes.data_as(C.c_void_p), tptrs, tlens.ctypes.data_as(C.c_void_p),
+                                              int(bool(is_prefill)), out.ctypes.data_as(C.c_void_p),
+                                              None if logits is None else logits.ctypes.data_as(C.c_void_p)),
+                self.model.h)
+        toks = [int(t) for t in out]
+        return (toks, logits) if return_logits else toks
+
+    def close(self):
         return None

@@ -27,7 +27,7 @@ def test_struct_mirrors_match_the_header(pkg):
     L = pkg._lib
     lib = pkg.lib()
     assert C.sizeof(L.ModelConfigC) == lib.nvl_sizeof(0) == 104     # 13 x i32, pad, f64, f32, i32, 3 x i32, 4 x f32, pad
-    assert C.sizeof(L.RuntimeOptsC) == lib.nvl_sizeof(1) == 32
+    assert C.sizeof(L.RuntimeOptsC) == lib.nvl_sizeof(1) == 40
     assert C.sizeof(L.StatsC) == lib.nvl_sizeof(2) == 14 * 8
     assert C.sizeof(L.SamplingParamsC) == lib.nvl_sizeof(3) == 16
     assert [n for n, _ in L.ModelConfigC._fields_][:3] == ["vocab_size", "hidden", "num_layers"]
