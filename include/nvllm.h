@@ -135,6 +135,18 @@ int nvl_create(const nvl_model_config* cfg, const nvl_runtime_opts* opts, nvl_mo
 int nvl_upload_tensor(nvl_model* m, int kind, int layer, const void* data, int dtype,
                       int64_t rows, int64_t cols, int layout);
 
+/* Replaces tensor.LoadModelFromDirectory / LoadModel / LoadShardedModel (generic_loader.go:184-265, 1016-1163): `path`
+ * is a .safetensors file, or a directory holding model.safetensors or model.safetensors.index.json + shards.  The
+ * file is mmap'ed and every weight is handed to the device in the checkpoint's dtype (F32/F16/BF16) and [out, in]
+ * layout: no fp32 host copy of the model, no host transposes.  The WeightMapping (:60-181) is chosen from the
+ * checkpoint's tensor names (GPT-2 / Falcon / Llama / Granite-MoE); names are also tried with a "transformer."
+ * prefix (:622-629).  Call between nvl_create and nvl_finalize. */
+int nvl_load_safetensors(nvl_model* m, const char* path);
+/* LoadModelConfig (generic_loader.go:808-972) over the New*Config templates (config.go:125-376): HF config.json (or
+ * the reference's model_info.json) -> nvl_model_config.  Reference quirks kept: max_position_embeddings and
+ * rope_scaling are not read.  Errors are reported through nvl_last_error(NULL). */
+int nvl_load_config_json(const char* path, nvl_model_config* cfg);
+
 /* Helpers for checkpoints that keep fused projections (generic_loader.go:674-765):
  * GPT-2 c_attn [H, 3H] split by columns; Falcon query_key_value given in the reference's
  * post-transpose form [H, (nH+2)*hd]; both fp32, host pointers. */

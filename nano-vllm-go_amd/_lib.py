@@ -103,6 +103,8 @@ def lib():
     L.nvl_upload_tensor.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, i64, i64, C.c_int]
     L.nvl_upload_gpt2_qkv.argtypes = [vp, C.c_int, vp, vp]
     L.nvl_upload_falcon_qkv.argtypes = [vp, C.c_int, vp]
+    L.nvl_load_safetensors.argtypes = [vp, C.c_char_p]
+    L.nvl_load_config_json.argtypes = [C.c_char_p, C.POINTER(ModelConfigC)]
     L.nvl_finalize.argtypes = [vp]
     L.nvl_destroy.argtypes = [vp]
     L.nvl_destroy.restype = None

@@ -1,0 +1,436 @@
+// loader.h — safetensors -> device, without the reference's fp32 host expansion and host transposes
+// (SURVEY §8 f-2).  Host-only C++; included at the end of nvllm.hip.
+//
+// Replaces tensor.LoadModelFromDirectory / LoadModel / LoadShardedModel (purego/tensor/generic_loader.go:184-265,
+// 1016-1163) and LoadModelConfig (:808-972).  The checkpoint is mmap'ed; every 2-D weight goes to nvl_upload_tensor
+// in the checkpoint's own dtype (F32 / F16 / BF16, :645-663) and PyTorch [out, in] layout — the dtype conversion,
+// the [in, out] view the reference builds with Transpose (:398-403, :533-552) and the tiling into the kernels'
+// operand layout all happen on the device.  Only the fused projections go through a host fp32 copy (GPT-2 c_attn,
+// Falcon query_key_value: split rules of :674-748), because their split is defined on the fp32 [in, out] matrix.
+// Differences from the reference, on purpose: sharded checkpoints may hold MoE layers (the reference's shard path has
+// none, :1270-1273); a tensor is looked up under its name and under "transformer." + name in every file (:622-629).
+#pragma once
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace nvl_loader {
+
+// ---------------------------------------------------------------------------------------------
+// JSON (just what config.json / safetensors headers need)
+// ---------------------------------------------------------------------------------------------
+struct JVal {
+    enum Kind { NUL, BOOL, NUM, STR, ARR, OBJ } kind = NUL;
+    bool b = false;
+    double num = 0;
+    std::string str;
+    std::vector<JVal> arr;
+    std::vector<std::pair<std::string, JVal>> obj;
+    const JVal* get(const std::string& k) const {
+        if (kind != OBJ) return nullptr;
+        for (auto& kv : obj) if (kv.first == k) return &kv.second;
+        return nullptr;
+    }
+};
+
+struct JParser {
+    const char* p; const char* end;
+    JParser(const char* s, size_t n) : p(s), end(s + n) {}
+    [[noreturn]] void bad(const char* what) { throw std::runtime_error(std::string("json: ") + what); }
+    void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
+    JVal parse() { ws(); JVal v = value(); ws(); return v; }
+    JVal value() {
+        if (p >= end) bad("unexpected end");
+        JVal v;
+        switch (*p) {
+            case '{': {
+                v.kind = JVal::OBJ; p++; ws();
+                if (p < end && *p == '}') { p++; return v; }
+                for (;;) {
+                    ws();
+                    if (p >= end || *p != '"') bad("expected a key");
+                    std::string k = string();
+                    ws();
+                    if (p >= end || *p != ':') bad("expected ':'");
+                    p++; ws();
+                    v.obj.emplace_back(std::move(k), value());
+                    ws();
+                    if (p < end && *p == ',') { p++; continue; }
+                    if (p < end && *p == '}') { p++; return v; }
+                    bad("expected ',' or '}'");
+                }
+            }
+            case '[': {
+                v.kind = JVal::ARR; p++; ws();
+                if (p < end && *p == ']') { p++; return v; }
+                for (;;) {
+                    ws();
+                    v.arr.push_back(value());
+                    ws();
+                    if (p < end && *p == ',') { p++; continue; }
+                    if (p < end && *p == ']') { p++; return v; }
+                    bad("expected ',' or ']'");
+                }
+            }
+            case '"': v.kind = JVal::STR; v.str = string(); return v;
+            case 't': lit("true"); v.kind = JVal::BOOL; v.b = true; return v;
+            case 'f': lit("false"); v.kind = JVal::BOOL; v.b = false; return v;
+            case 'n': lit("null"); return v;
+            default: {
+                char* e = nullptr;
+                v.num = std::strtod(p, &e);          // (headers are NUL-terminated copies: strtod cannot run off the end)
+                if (e == p) bad("unexpected character");
+                v.kind = JVal::NUM; p = e; return v;
+            }
+        }
+    }
+    void lit(const char* s) { const size_t n = strlen(s); if ((size_t)(end - p) < n || strncmp(p, s, n) != 0) bad("bad literal"); p += n; }
+    std::string string() {
+        std::string out; p++;
+        while (p < end && *p != '"') {
+            if (*p == '\\') {
+                if (++p >= end) bad("bad escape");
+                switch (*p) {
+                    case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break;
+                    case 'b': out += '\b'; break; case 'f': out += '\f'; break;
+                    case 'u': {     // keep BMP code points as UTF-8; names in checkpoints are ASCII anyway
+                        if (end - p < 5) bad("bad \\u escape");
+                        const unsigned cp = (unsigned)std::strtoul(std::string(p + 1, 4).c_str(), nullptr, 16);
+                        if (cp < 0x80) out += (char)cp;
+                        else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 63)); }
+                        else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 63)); out += (char)(0x80 | (cp & 63)); }
+                        p += 4; break;
+                    }
+                    default: out += *p;
+                }
+                p++;
+            } else out += *p++;
+        }
+        if (p >= end) bad("unterminated string");
+        p++;
+        return out;
+    }
+};
+
+inline std::string read_text(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::string s; char buf[1 << 16]; size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, n);
+    fclose(f);
+    return s;
+}
+inline bool exists(const std::string& path, bool* is_dir = nullptr) {
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) return false;
+    if (is_dir) *is_dir = S_ISDIR(st.st_mode);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// safetensors: 8-byte LE header length, JSON header {name: {dtype, shape, data_offsets}}, raw little-endian data
+// (generic_loader.go:184-199, loader.go:13-17)
+// ---------------------------------------------------------------------------------------------
+struct StTensor { const uint8_t* data = nullptr; int dtype = 0; std::vector<int64_t> shape; size_t bytes = 0; int64_t numel = 1; };
+
+struct StFile {
+    int fd = -1; void* map = MAP_FAILED; size_t size = 0;
+    ~StFile() { if (map != MAP_FAILED) munmap(map, size); if (fd >= 0) close(fd); }
+};
+
+struct StSet {
+    std::vector<std::unique_ptr<StFile>> files;
+    std::map<std::string, StTensor> tensors;
+
+    void add_file(const std::string& path) {
+        std::unique_ptr<StFile> f(new StFile);
+        f->fd = open(path.c_str(), O_RDONLY);
+        if (f->fd < 0) throw std::runtime_error("cannot open " + path);
+        struct stat st; fstat(f->fd, &st); f->size = (size_t)st.st_size;
+        if (f->size < 8) throw std::runtime_error(path + ": not a safetensors file");
+        f->map = mmap(nullptr, f->size, PROT_READ, MAP_PRIVATE, f->fd, 0);
+        if (f->map == MAP_FAILED) throw std::runtime_error("mmap failed for " + path);
+        const uint8_t* base = (const uint8_t*)f->map;
+        uint64_t hlen = 0; memcpy(&hlen, base, 8);
+        if (hlen > f->size - 8) throw std::runtime_error(path + ": header length exceeds the file");
+        const std::string header((const char*)base + 8, (size_t)hlen);
+        const JVal root = JParser(header.c_str(), header.size()).parse();
+        if (root.kind != JVal::OBJ) throw std::runtime_error(path + ": header is not a JSON object");
+        const uint8_t* data = base + 8 + hlen;
+        const size_t data_len = f->size - 8 - (size_t)hlen;
+        for (auto& kv : root.obj) {
+            if (kv.first == "__metadata__") continue;
+            const JVal *dt = kv.second.get("dtype"), *sh = kv.second.get("shape"), *off = kv.second.get("data_offsets");
+            if (!dt || !sh || !off || off->arr.size() != 2) throw std::runtime_error(path + ": malformed entry " + kv.first);
+            StTensor t;
+            if (dt->str == "F32") t.dtype = NVL_DTYPE_F32; else if (dt->str == "BF16") t.dtype = NVL_DTYPE_BF16;
+            else if (dt->str == "F16") t.dtype = NVL_DTYPE_F16; else t.dtype = -1;      // refused only if the model needs it (:660-662)
+            for (auto& d : sh->arr) { t.shape.push_back((int64_t)d.num); t.numel *= (int64_t)d.num; }
+            const size_t b = (size_t)off->arr[0].num, e = (size_t)off->arr[1].num;
+            if (e < b || e > data_len) throw std::runtime_error(path + ": data_offsets of " + kv.first + " outside the file");
+            t.data = data + b; t.bytes = e - b;
+            if (t.dtype >= 0 && t.bytes != (size_t)t.numel * (t.dtype == NVL_DTYPE_F32 ? 4 : 2))
+                throw std::runtime_error(path + ": byte size of " + kv.first + " does not match its shape");
+            tensors[kv.first] = std::move(t);
+        }
+        files.push_back(std::move(f));
+    }
+    // a file, or a directory with model.safetensors or model.safetensors.index.json + shards (:1016-1040, :1042-1075)
+    void open_path(const std::string& path) {
+        bool dir = false;
+        if (!exists(path, &dir)) throw std::runtime_error("no such file or directory: " + path);
+        if (!dir) { add_file(path); return; }
+        const std::string idx = path + "/model.safetensors.index.json";
+        if (exists(idx)) {
+            const std::string txt = read_text(idx);
+            const JVal root = JParser(txt.c_str(), txt.size()).parse();
+            const JVal* wm = root.get("weight_map");
+            if (!wm || wm->kind != JVal::OBJ) throw std::runtime_error(idx + ": no weight_map");
+            std::vector<std::string> shards;
+            for (auto& kv : wm->obj)
+                if (std::find(shards.begin(), shards.end(), kv.second.str) == shards.end()) shards.push_back(kv.second.str);
+            for (auto& s : shards) add_file(path + "/" + s);
+            return;
+        }
+        add_file(path + "/model.safetensors");
+    }
+    const StTensor* find(const std::string& name) const {           // :619-632
+        auto it = tensors.find(name);
+        if (it == tensors.end()) it = tensors.find("transformer." + name);
+        return it == tensors.end() ? nullptr : &it->second;
+    }
+    const StTensor& need(const std::string& name) const {
+        const StTensor* t = find(name);
+        if (!t) throw std::runtime_error("required tensor '" + name + "' not found (also tried: transformer." + name + ")");
+        if (t->dtype < 0) throw std::runtime_error("unsupported dtype for tensor '" + name + "'");
+        return *t;
+    }
+};
+
+inline float f32_of(const StTensor& t, int64_t i) {                  // :769-805
+    if (t.dtype == NVL_DTYPE_F32) { float f; memcpy(&f, t.data + i * 4, 4); return f; }
+    uint16_t h; memcpy(&h, t.data + i * 2, 2);
+    uint32_t u;
+    if (t.dtype == NVL_DTYPE_BF16) u = (uint32_t)h << 16;
+    else {
+        const uint32_t s = (h >> 15) & 1u, e = (h >> 10) & 31u, m = h & 1023u;
+        if (e == 0) {
+            if (m == 0) u = s << 31;
+            else { int k = 0; uint32_t mm = m; while (!(mm & 1024u)) { mm <<= 1; k++; } u = (s << 31) | ((uint32_t)(113 - k) << 23) | ((mm & 1023u) << 13); }
+        } else if (e == 31) u = (s << 31) | 0x7F800000u | (m << 13);
+        else u = (s << 31) | ((e + 112u) << 23) | (m << 13);
+    }
+    float f; memcpy(&f, &u, 4); return f;
+}
+
+}  // namespace nvl_loader
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+namespace {
+using nvl_loader::StSet; using nvl_loader::StTensor; using nvl_loader::JVal;
+
+void up2d(nvl_model* m, int kind, int layer, const StTensor& t, int layout) {
+    if (t.shape.size() != 2) throw std::runtime_error("loader: a 2-D tensor was expected");
+    const int rc = nvl_upload_tensor(m, kind, layer, t.data, t.dtype, t.shape[0], t.shape[1], layout);
+    if (rc) throw std::runtime_error(std::string("loader: ") + nvl_last_error(m));
+}
+void up1d(nvl_model* m, int kind, int layer, const StTensor& t) {
+    const int rc = nvl_upload_tensor(m, kind, layer, t.data, t.dtype, t.numel, 1, NVL_LAYOUT_IN_OUT);
+    if (rc) throw std::runtime_error(std::string("loader: ") + nvl_last_error(m));
+}
+// loadNorm (:595-604): weight required, bias (".weight" -> ".bias") optional
+void load_norm(nvl_model* m, const StSet& st, const std::string& key, int kind_w, int kind_b, int layer) {
+    up1d(m, kind_w, layer, st.need(key));
+    std::string bk = key;
+    const size_t p = bk.find(".weight");
+    if (p != std::string::npos) bk.replace(p, 7, ".bias");
+    if (const StTensor* b = st.find(bk)) if (b->dtype >= 0) up1d(m, kind_b, layer, *b);
+}
+std::vector<float> to_f32(const StTensor& t) {
+    std::vector<float> v((size_t)t.numel);
+    for (int64_t i = 0; i < t.numel; i++) v[(size_t)i] = nvl_loader::f32_of(t, i);
+    return v;
+}
+}  // namespace
+
+extern "C" int nvl_load_safetensors(nvl_model* m, const char* path) {
+    if (!m || !path) return NVL_ERR_INVALID;
+    if (m->finalized) return fail(m, NVL_ERR_STATE, "nvl_load_safetensors: model already finalized");
+    NVL_TRY(m)
+    StSet st;
+    st.open_path(path);
+    const nvl_model_config& c = m->cfg;
+    // which WeightMapping (:60-181) — told from the checkpoint's own names
+    const bool gpt2 = st.find("wte.weight") != nullptr;
+    const bool falcon = st.find("transformer.word_embeddings.weight") != nullptr || st.find("word_embeddings.weight") != nullptr;
+    const bool llama = st.find("model.embed_tokens.weight") != nullptr;       // Llama and Granite-MoE share the naming
+    if (gpt2 + falcon + llama != 1) throw std::runtime_error("nvl_load_safetensors: cannot tell the architecture from the tensor names");
+    const int OI = NVL_LAYOUT_OUT_IN, IO = NVL_LAYOUT_IN_OUT;
+
+    if (gpt2) {                                                                // GetGPT2Mapping (:60-78): weights already [in, out]
+        up2d(m, NVL_T_TOK_EMB, 0, st.need("wte.weight"), IO);
+        if (const StTensor* pe = st.find("wpe.weight")) up2d(m, NVL_T_POS_EMB, 0, *pe, IO);
+        for (int l = 0; l < c.num_layers; l++) {
+            const std::string p = "h." + std::to_string(l);
+            const std::vector<float> w = to_f32(st.need(p + ".attn.c_attn.weight"));     // splitGPT2QKV (:674-702)
+            std::vector<float> b;
+            if (const StTensor* bt = st.find(p + ".attn.c_attn.bias")) b = to_f32(*bt);
+            if (nvl_upload_gpt2_qkv(m, l, w.data(), b.empty() ? nullptr : b.data())) throw std::runtime_error(nvl_last_error(m));
+            up2d(m, NVL_T_WO, l, st.need(p + ".attn.c_proj.weight"), IO);
+            if (const StTensor* bo = st.find(p + ".attn.c_proj.bias")) up1d(m, NVL_T_BO, l, *bo);
+            up2d(m, NVL_T_W1, l, st.need(p + ".mlp.c_fc.weight"), IO);
+            up2d(m, NVL_T_W2, l, st.need(p + ".mlp.c_proj.weight"), IO);
+            // (the FFN biases are looked up as "...c_fc.weight.bias" by the reference and never found: :559-560 — not loaded)
+            load_norm(m, st, p + ".ln_1.weight", NVL_T_ATTN_NORM_W, NVL_T_ATTN_NORM_B, l);
+            load_norm(m, st, p + ".ln_2.weight", NVL_T_FFN_NORM_W, NVL_T_FFN_NORM_B, l);
+        }
+        load_norm(m, st, "ln_f.weight", NVL_T_FINAL_NORM_W, NVL_T_FINAL_NORM_B, 0);
+    } else if (falcon) {                                                       // GetFalconMapping (:81-98): PyTorch [out, in]
+        up2d(m, NVL_T_TOK_EMB, 0, st.need("transformer.word_embeddings.weight"), IO);
+        for (int l = 0; l < c.num_layers; l++) {
+            const std::string p = "transformer.h." + std::to_string(l);
+            const StTensor& qkv = st.need(p + ".self_attention.query_key_value.weight");   // [(nH+2)*hd, H]
+            if (qkv.shape.size() != 2) throw std::runtime_error("query_key_value: 2-D expected");
+            const int64_t R = qkv.shape[0], K = qkv.shape[1];
+            std::vector<float> t((size_t)(R * K));                             // Transpose BEFORE splitting (:366-369)
+            for (int64_t r = 0; r < R; r++)
+                for (int64_t k = 0; k < K; k++) t[(size_t)(k * R + r)] = nvl_loader::f32_of(qkv, r * K + k);
+            if (nvl_upload_falcon_qkv(m, l, t.data())) throw std::runtime_error(nvl_last_error(m));
+            up2d(m, NVL_T_WO, l, st.need(p + ".self_attention.dense.weight"), OI);
+            up2d(m, NVL_T_W1, l, st.need(p + ".mlp.dense_h_to_4h.weight"), OI);
+            up2d(m, NVL_T_W2, l, st.need(p + ".mlp.dense_4h_to_h.weight"), OI);
+            load_norm(m, st, p + ".input_layernorm.weight", NVL_T_ATTN_NORM_W, NVL_T_ATTN_NORM_B, l);   // parallel block: InputLN
+        }
+        load_norm(m, st, "transformer.ln_f.weight", NVL_T_FINAL_NORM_W, NVL_T_FINAL_NORM_B, 0);
+        if (!c.tied_embedding) if (const StTensor* lm = st.find("lm_head.weight")) up2d(m, NVL_T_LM_HEAD, 0, *lm, OI);
+    } else {                                                                   // GetLlamaMapping / GetGraniteMoEMapping (:101-141)
+        up2d(m, NVL_T_TOK_EMB, 0, st.need("model.embed_tokens.weight"), IO);
+        for (int l = 0; l < c.num_layers; l++) {
+            const std::string p = "model.layers." + std::to_string(l);
+            up2d(m, NVL_T_WQ, l, st.need(p + ".self_attn.q_proj.weight"), OI);
+            up2d(m, NVL_T_WK, l, st.need(p + ".self_attn.k_proj.weight"), OI);
+            up2d(m, NVL_T_WV, l, st.need(p + ".self_attn.v_proj.weight"), OI);
+            up2d(m, NVL_T_WO, l, st.need(p + ".self_attn.o_proj.weight"), OI);
+            if (c.use_moe) {                                                   // loadMoE (:566-592)
+                up2d(m, NVL_T_ROUTER, l, st.need(p + ".block_sparse_moe.router.layer.weight"), OI);   // [E, H]: "always transpose"
+                for (int which = 0; which < 2; which++) {
+                    const StTensor& e = st.need(p + (which ? ".block_sparse_moe.output_linear.weight" : ".block_sparse_moe.input_linear.weight"));
+                    if (e.shape.size() != 3) throw std::runtime_error("expert weights: 3-D [E, out, in] expected");
+                    const int rc = nvl_upload_tensor(m, which ? NVL_T_MOE_OUT : NVL_T_MOE_IN, l, e.data, e.dtype,
+                                                     e.shape[0] * e.shape[1], e.shape[2], IO);
+                    if (rc) throw std::runtime_error(nvl_last_error(m));
+                }
+            } else {                                                           // loadFFN (:513-563): gate | up -> W1
+                const StTensor& g = st.need(p + ".mlp.gate_proj.weight");
+                const StTensor* u = st.find(p + ".mlp.up_proj.weight");
+                if (u) {
+                    if (u->dtype != g.dtype || u->shape != g.shape || g.shape.size() != 2) throw std::runtime_error("gate_proj / up_proj mismatch");
+                    std::vector<uint8_t> cat(g.bytes + u->bytes);              // [2F, H] in the checkpoint's dtype == ([H, F] | [H, F])^T
+                    memcpy(cat.data(), g.data, g.bytes);
+                    memcpy(cat.data() + g.bytes, u->data, u->bytes);
+                    const int rc = nvl_upload_tensor(m, NVL_T_W1, l, cat.data(), g.dtype, 2 * g.shape[0], g.shape[1], OI);
+                    if (rc) throw std::runtime_error(nvl_last_error(m));
+                } else {
+                    up2d(m, NVL_T_W1, l, g, OI);                               // a checkpoint with the pair already fused
+                }
+                up2d(m, NVL_T_W2, l, st.need(p + ".mlp.down_proj.weight"), OI);
+            }
+            load_norm(m, st, p + ".input_layernorm.weight", NVL_T_ATTN_NORM_W, NVL_T_ATTN_NORM_B, l);
+            load_norm(m, st, p + ".post_attention_layernorm.weight", NVL_T_FFN_NORM_W, NVL_T_FFN_NORM_B, l);
+        }
+        load_norm(m, st, "model.norm.weight", NVL_T_FINAL_NORM_W, NVL_T_FINAL_NORM_B, 0);
+        // LM head (:245-258): own matrix unless tied; a missing one falls back to the transposed embedding
+        if (!c.tied_embedding) if (const StTensor* lm = st.find("lm_head.weight")) up2d(m, NVL_T_LM_HEAD, 0, *lm, OI);
+    }
+    NVL_HIP(hipStreamSynchronize(m->stream));   // the mmaps go away when `st` does
+    return NVL_OK;
+    NVL_CATCH(m)
+}
+
+// LoadModelConfig (generic_loader.go:808-972) on top of the New*Config templates (config.go:125-376)
+extern "C" int nvl_load_config_json(const char* path, nvl_model_config* out) {
+    if (!path || !out) return NVL_ERR_INVALID;
+    try {
+        const std::string txt = nvl_loader::read_text(path);
+        const JVal raw = nvl_loader::JParser(txt.c_str(), txt.size()).parse();
+        if (raw.kind != JVal::OBJ) throw std::runtime_error("config is not a JSON object");
+        auto str = [&](const char* k) { const JVal* v = raw.get(k); return v && v->kind == JVal::STR ? v->str : std::string(); };
+        auto num = [&](const char* k, double& dst) { const JVal* v = raw.get(k); if (v && v->kind == JVal::NUM) { dst = v->num; return true; } return false; };
+        nvl_model_config c;
+        memset(&c, 0, sizeof c);
+        // ---- templates (config.go:125-376); `architecture` first, then model_type (:822-836, :975-1007), default GPT-2
+        std::string arch = str("architecture");
+        const std::string mt = str("model_type");
+        if (arch != "gpt2" && arch != "falcon" && arch != "llama") {
+            if (mt == "gpt2") arch = "gpt2";
+            else if (mt == "falcon" || mt == "RefinedWeb" || mt == "RefinedWebModel") arch = "falcon";
+            else if (mt == "llama" || mt == "LlamaForCausalLM") arch = "llama";
+            else if (mt == "granitemoe") arch = "granitemoe";
+            else if (mt == "granitemoehybrid") throw std::runtime_error("granitemoehybrid (Mamba2 layers) is outside this library's scope");
+            else arch = "gpt2";
+        }
+        c.rope_base = 10000.0; c.norm_eps = 1e-5f;
+        if (arch == "gpt2") {            // NewGPT2Config (config.go:125-148)
+            c.vocab_size = 50257; c.hidden = 768; c.num_layers = 12; c.num_heads = 12; c.num_kv_heads = 12; c.head_dim = 64; c.ffn_dim = 3072;
+            c.max_seq_len = 1024; c.attention_type = NVL_ATTN_MHA; c.norm_type = NVL_NORM_LAYER; c.position_type = NVL_POS_LEARNED;
+            c.activation_type = NVL_ACT_GELU; c.block_style = NVL_BLOCK_SEQUENTIAL; c.tied_embedding = 1;
+        } else if (arch == "falcon") {   // NewFalconConfig("7b") (config.go:151-194)
+            c.vocab_size = 65024; c.hidden = 4544; c.num_layers = 32; c.num_heads = 71; c.num_kv_heads = 1; c.head_dim = 64; c.ffn_dim = 18176;
+            c.max_seq_len = 2048; c.attention_type = NVL_ATTN_MQA; c.norm_type = NVL_NORM_LAYER; c.position_type = NVL_POS_ROPE;
+            c.activation_type = NVL_ACT_GELU; c.block_style = NVL_BLOCK_PARALLEL; c.tied_embedding = 0;
+        } else if (arch == "llama") {    // NewLlamaConfig("7b") (config.go:197-242)
+            c.vocab_size = 32000; c.hidden = 4096; c.num_layers = 32; c.num_heads = 32; c.num_kv_heads = 8; c.head_dim = 128; c.ffn_dim = 11008;
+            c.max_seq_len = 4096; c.attention_type = NVL_ATTN_GQA; c.norm_type = NVL_NORM_RMS; c.position_type = NVL_POS_ROPE;
+            c.activation_type = NVL_ACT_SWIGLU; c.block_style = NVL_BLOCK_SEQUENTIAL; c.tied_embedding = 0; c.norm_eps = 1e-6f;
+        } else {                         // NewGraniteMoEConfig("350m") (config.go:333-376); use_moe comes from num_local_experts
+            c.vocab_size = 49155; c.hidden = 1024; c.num_layers = 24; c.num_heads = 16; c.num_kv_heads = 8; c.head_dim = 64; c.ffn_dim = 512;
+            c.max_seq_len = 4096; c.attention_type = NVL_ATTN_GQA; c.norm_type = NVL_NORM_RMS; c.position_type = NVL_POS_ROPE;
+            c.activation_type = NVL_ACT_SWIGLU; c.block_style = NVL_BLOCK_SEQUENTIAL; c.tied_embedding = 1; c.norm_eps = 1e-6f;
+            c.use_moe = 0; c.num_experts = 32; c.num_experts_per_tok = 8;
+        }
+        // ---- overrides, in the reference's order (:838-968)
+        double v;
+        if (num("vocab_size", v)) c.vocab_size = (int)v;
+        if (num("n_embd", v)) c.hidden = (int)v;
+        if (num("hidden_size", v)) c.hidden = (int)v;
+        if (num("n_layer", v)) c.num_layers = (int)v;
+        if (num("num_hidden_layers", v)) c.num_layers = (int)v;
+        if (num("num_layers", v)) c.num_layers = (int)v;
+        if (num("n_head", v)) c.num_heads = (int)v;
+        if (num("num_attention_heads", v)) c.num_heads = (int)v;
+        if (num("num_heads", v)) c.num_heads = (int)v;
+        if (num("num_key_value_heads", v)) c.num_kv_heads = (int)v;
+        if (num("num_kv_heads", v)) c.num_kv_heads = (int)v;
+        if (const JVal* mq = raw.get("multi_query")) if (mq->kind == JVal::BOOL && mq->b) c.num_kv_heads = 1;
+        if (num("head_dim", v)) c.head_dim = (int)v;
+        if (c.head_dim == 0 && c.hidden > 0 && c.num_heads > 0) c.head_dim = c.hidden / c.num_heads;   // (:884-886)
+        if (num("rope_theta", v)) c.rope_base = v;
+        if (num("rms_norm_eps", v)) c.norm_eps = (float)v;
+        if (num("layer_norm_epsilon", v)) c.norm_eps = (float)v;
+        if (num("n_inner", v)) c.ffn_dim = (int)v;
+        if (num("intermediate_size", v)) c.ffn_dim = (int)v;
+        if (c.ffn_dim == 0 && c.hidden > 0) c.ffn_dim = 4 * c.hidden;
+        if (const JVal* t = raw.get("tie_word_embeddings")) if (t->kind == JVal::BOOL) c.tied_embedding = t->b ? 1 : 0;
+        if (num("embedding_multiplier", v)) c.embedding_multiplier = (float)v;
+        if (num("attention_multiplier", v)) c.attention_multiplier = (float)v;
+        if (num("residual_multiplier", v)) c.residual_multiplier = (float)v;
+        if (num("logits_scaling", v)) c.logits_scaling = (float)v;
+        if (num("num_local_experts", v)) { c.num_experts = (int)v; c.use_moe = 1; }
+        if (num("num_experts_per_tok", v)) c.num_experts_per_tok = (int)v;
+        *out = c;
+        return NVL_OK;
+    } catch (const std::exception& e) {
+        g_create_err = std::string("nvl_load_config_json: ") + e.what();
+        return NVL_ERR_INVALID;
+    }
+}

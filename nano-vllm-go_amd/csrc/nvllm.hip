@@ -1680,3 +1680,4 @@ int runner_impl(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t*
 }  // namespace
 
 #include "ops_impl.h"
+#include "loader.h"

@@ -63,6 +63,31 @@ class HipTransformerModel:
                 self.upload(slot, layer, arr)
             self.finalize()
 
+    @classmethod
+    def from_pretrained(cls, path: str, **kw):
+        """tensor.LoadModelFromDirectory (generic_loader.go:1016-1040) without the fp32 host model: config.json (or
+        model_info.json) through nvl_load_config_json, weights through nvl_load_safetensors (mmap -> device)."""
+        import os
+        c = L.ModelConfigC()
+        for name in ("config.json", "model_info.json"):
+            cp = os.path.join(path, name)
+            if os.path.exists(cp):
+                L.check(L.lib().nvl_load_config_json(cp.encode(), C.byref(c)))
+                break
+        else:
+            raise FileNotFoundError(f"no config.json / model_info.json in {path}")
+        inv = {k: {v: n for n, v in tbl.items()} for k, tbl in
+               (("attention_type", L.ATTN), ("norm_type", L.NORM), ("position_type", L.POS),
+                ("activation_type", L.ACT), ("block_style", L.BLOCK))}
+        cfg = {}
+        for name, _ in L.ModelConfigC._fields_:
+            v = getattr(c, name)
+            cfg[name] = inv[name][v] if name in inv else (bool(v) if name in ("tied_embedding", "use_moe") else v)
+        m = cls(cfg, None, **kw)
+        L.check(m.lib.nvl_load_safetensors(m.h, path.encode()), m.h)
+        m.finalize()
+        return m
+
     def finalize(self):
         L.check(self.lib.nvl_finalize(self.h), self.h)
 

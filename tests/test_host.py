@@ -67,3 +67,50 @@ def test_sequence_and_sharding(pkg):
     assert sorted(i for p in parts for i in p) == list(range(len(ids)))       # a partition
     assert all(pkg.dist.owner(ids[i], 4) == r for r, p in enumerate(parts) for i in p)
     assert pkg.dist.shard(ids, 0, 1) == list(range(6))
+
+
+def test_native_config_loader_matches_python_mirror(pkg, tmp_path):
+    """nvl_load_config_json (C++: LoadModelConfig generic_loader.go:808-972 over the config.go templates) against the
+    Python mirror of the same function, on HF-style configs of every family incl. the reference's quirks."""
+    import ctypes as C
+    import json
+    L = pkg._lib
+    cases = [
+        dict(model_type="llama", vocab_size=128256, hidden_size=2048, num_hidden_layers=16, num_attention_heads=32,
+             num_key_value_heads=8, head_dim=64, intermediate_size=8192, rope_theta=500000.0, rms_norm_eps=1e-5,
+             tie_word_embeddings=True, max_position_embeddings=131072, rope_scaling={"factor": 32.0}),
+        dict(model_type="gpt2", vocab_size=50257, n_embd=1024, n_layer=24, n_head=16, n_inner=None, layer_norm_epsilon=1e-5),
+        dict(model_type="RefinedWebModel", vocab_size=65024, hidden_size=4544, n_layer=32, n_head=71, multi_query=True,
+             layer_norm_epsilon=1e-5),
+        dict(model_type="granitemoe", vocab_size=49155, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+             num_key_value_heads=8, intermediate_size=512, num_local_experts=32, num_experts_per_tok=8,
+             embedding_multiplier=12.0, attention_multiplier=0.015625, residual_multiplier=0.22, logits_scaling=6.0,
+             tie_word_embeddings=True, rms_norm_eps=1e-6, rope_theta=10000),
+        dict(architecture="llama", hidden_size=512, num_heads=8, num_kv_heads=2, num_layers=4),
+        dict(some_unknown_thing=1),                                  # default: GPT-2 template (:1005)
+    ]
+    enum = dict(attention_type=["mha", "mqa", "gqa"], norm_type=["layernorm", "rmsnorm"],
+                position_type=["learned", "rope", "nope"], activation_type=["gelu", "swiglu"],
+                block_style=["sequential", "parallel"])
+    for i, raw in enumerate(cases):
+        p = tmp_path / f"c{i}.json"
+        p.write_text(json.dumps(raw) + "\n")
+        got = L.ModelConfigC()
+        L.check(L.lib().nvl_load_config_json(str(p).encode(), C.byref(got)))
+        want = pkg.config.load_model_config(raw)
+        for name, _ in L.ModelConfigC._fields_:
+            if name.startswith("_"):
+                continue
+            g, w = getattr(got, name), getattr(want, name)
+            if name in enum:
+                assert enum[name][g] == w, (i, name)
+            elif isinstance(w, bool):
+                assert bool(g) == w, (i, name)
+            elif isinstance(w, float):
+                assert abs(g - w) <= 1e-6 * max(1.0, abs(w)), (i, name, g, w)
+            else:
+                assert g == w, (i, name, g, w)
+    bad = tmp_path / "bad.json"
+    bad.write_text("{\"a\": [1, 2,")
+    assert L.lib().nvl_load_config_json(str(bad).encode(), C.byref(L.ModelConfigC())) < 0
+    assert L.lib().nvl_load_config_json(str(tmp_path / "missing.json").encode(), C.byref(L.ModelConfigC())) < 0
