@@ -337,7 +337,8 @@ int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int 
  * 1 = 128x128 two-stage, 2 = 256x128 three-stage, 3 = 256x256 two-stage, 4 = 256x256 pipelined).
  * key 1: K slices of the decode residual projections (0 automatic, 1 never split, 2, 4).
  * key 2: decode (M <= 64) GEMM form: 0 automatic, 1/2/4 = narrow form with that many weight tiles per workgroup,
- * 8 = wide-N form (4 weight tiles per wave).  Returns the previous value. */
+ * 8 = wide-N form (4 weight tiles per wave).
+ * key 3: deferred RMSNorm between the decode O-projection and FFN-up (1 on, 0 off).  Returns the previous value. */
 int nvl_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -74,6 +74,19 @@ struct GemmArgs {
     // The kernel boundary is the synchronisation: no fences, no atomics, fixed summation order.
     float* sk_part;
     int sk_slices;
+    // Deferred RMSNorm (decode; RMSNorm + SwiGLU, sequential block): the residual projection that completes x also
+    // emits the NEXT projection's operand un-normalised, xn_raw = bf16(x * w_norm) (fragment-major), plus the sums of
+    // x^2 over its 16 columns, rs_out[tile][m]; the consumer scales its accumulators by
+    // rstd[m] = 1 / sqrt(sum_tiles(rs_in[tile][m]) / H + eps) — (x*w/rms)·W == (1/rms)·((x*w)·W).  The norm launch
+    // between the two projections disappears; all sums keep a fixed order.
+    int m_split;            // narrow decode kernel: gridDim.y indexes 16-row activation tiles (not K slices): the
+                            // workgroups of a weight tile stream the same weights (one XCD: L2 serves the second)
+    const float* nrm_w;     // producer: weight of the norm that follows, [N]
+    bf16_t* nrm_xn;         // producer: xn_raw [M_pad16][N] fragment-major
+    float* rs_out;          // producer: [64 rows][N/16]
+    const float* rs_in;     // consumer: the same buffer
+    int rs_tiles;
+    float rs_inv_h, rs_eps;
 };
 
 __device__ __forceinline__ float silu_f(float g) { return g / (1.0f + __expf(-g)); }
@@ -84,12 +97,15 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     return 0.5f * x * (1.0f + tanhf(inner));
 }
 
+__device__ __forceinline__ float deferred_rstd(const GemmArgs& p, int m);
+
 // ------------------------------------------------------------------------------------------
 // epilogue shared by all kernels: 4 consecutive n for one row m
 // ------------------------------------------------------------------------------------------
 template <int EPI, typename OutT>
-__device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4 v) {
+__device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4 v, float rstd = 1.0f) {
     if (m >= p.M || n >= p.N) return;
+    v *= rstd;                       // deferred RMSNorm of the input row (1 otherwise), before the bias
     const bool full = (n + 3 < p.N);
     if (p.bias) {
 #pragma unroll
@@ -125,10 +141,27 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4
     }
 }
 
+// deferred RMSNorm scale of input row m (< 64): the 4 lanes that share a row (same lane & 15) split the tile partials.
+// Call with all 64 lanes active; 1 when the projection's operand is already normalised.
+__device__ __forceinline__ float deferred_rstd(const GemmArgs& p, int m) {
+    if (!p.rs_in) return 1.0f;
+    // rs_in is [64 rows][rs_tiles] (rs_tiles % 16 == 0): a lane sums a quarter of its row with independent 16-byte loads
+    const int per = p.rs_tiles >> 2;
+    const f32x4* src = (const f32x4*)(p.rs_in + (int64_t)m * p.rs_tiles + ((threadIdx.x & 63) >> 4) * per);
+    f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int q = 0; q < (per >> 2); q++) a4 += src[q];
+    float s = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    return 1.0f / sqrtf(s * p.rs_inv_h + p.rs_eps);
+}
+
 template <typename OutT>
-__device__ __forceinline__ void epilogue_swiglu4(const GemmArgs& p, int m, int f, f32x4 g, f32x4 u) {
+__device__ __forceinline__ void epilogue_swiglu4(const GemmArgs& p, int m, int f, f32x4 g, f32x4 u, float rstd = 1.0f) {
     // p.N counts fused rows (2F); the output has F = N/2 columns, ldc = F
     if (m >= p.M || f >= (p.N >> 1)) return;
+    g *= rstd; u *= rstd;
     f32x4 v;
 #pragma unroll
     for (int r = 0; r < 4; r++) v[r] = silu_f(g[r]) * u[r];
@@ -499,7 +532,9 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     const int nt0 = blockIdx.x * NTW;                // first 16-row weight tile of this workgroup
     // K/32 k-steps dealt over (gridDim.y slices) x (ksplit waves) as evenly as possible (K need not divide:
     // Falcon's 4544 = 142 steps)
-    const int nparts = ksplit * gridDim.y, part = blockIdx.y * ksplit + kw;
+    const int i_off = p.m_split ? blockIdx.y : 0;                  // first 16-row activation tile of this workgroup
+    const int nslices = p.m_split ? 1 : gridDim.y, slice = p.m_split ? 0 : blockIdx.y;
+    const int nparts = ksplit * nslices, part = slice * ksplit + kw;
     const int nks = p.K >> 5, q = nks / nparts, rr = nks - q * nparts;
     const int my_steps = q + (part < rr ? 1 : 0);
     const int ks0 = part * q + (part < rr ? part : rr);   // first k-step of this wave
@@ -508,7 +543,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     const bf16_t* xp[MT];
 #pragma unroll
     for (int i = 0; i < MT; i++)   // rows >= M of the last 16-row tile exist (padded allocation) and are never stored
-        xp[i] = (const bf16_t*)p.A + (((int64_t)i * (p.K >> 5) + ks0) * 64 + lane) * 8;
+        xp[i] = (const bf16_t*)p.A + (((int64_t)(i + i_off) * (p.K >> 5) + ks0) * 64 + lane) * 8;
     f32x4 acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -560,9 +595,9 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     if (EPI == EPI_SWIGLU) {
         for (int i = wave; i < MT; i += NTW * ksplit) {
             const int f = (nt0 >> 1) * 16 + 4 * fg;    // NTW == 2: tiles [gate 16 | up 16] of features 8*nt0..
-            epilogue_swiglu4<OutT>(p, 16 * i + fr, f, ksum(0, i), ksum(NTW - 1, i));
+            epilogue_swiglu4<OutT>(p, 16 * i + fr, f, ksum(0, i), ksum(NTW - 1, i), deferred_rstd(p, 16 * i + fr));
         }
-    } else if (EPI == EPI_RESID && gridDim.y > 1) {
+    } else if (EPI == EPI_RESID && nslices > 1) {
         // split-K across workgroups: publish the partial tile (slice 0 carries the bias); the following norm
         // kernel adds the slices into x in slice order
         for (int e = wave; e < NTW * MT; e += NTW * ksplit) {
@@ -570,13 +605,33 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
             const int m = 16 * i + fr, n = (nt0 + t) * 16 + 4 * fg;
             if (m >= p.M || n >= p.N) continue;
             f32x4 v = ksum(t, i);
-            if (p.bias && blockIdx.y == 0) v += *(const f32x4*)(p.bias + n);    // N % 4 == 0 for residual widths
-            *(f32x4*)(p.sk_part + ((int64_t)blockIdx.y * p.M + m) * p.N + n) = v;
+            if (p.bias && slice == 0) v += *(const f32x4*)(p.bias + n);    // N % 4 == 0 for residual widths
+            *(f32x4*)(p.sk_part + ((int64_t)slice * p.M + m) * p.N + n) = v;
+        }
+    } else if (EPI == EPI_RESID && p.rs_out) {
+        // x += alpha * (acc + bias) in place, and the deferred-RMSNorm operand + x^2 partials for the next projection
+        for (int e = wave; e < NTW * MT; e += NTW * ksplit) {
+            const int t = e / MT, i = e - t * MT;
+            const int m = 16 * (i + i_off) + fr, n = (nt0 + t) * 16 + 4 * fg;      // N % 16 == 0 (hidden width)
+            f32x4 v = ksum(t, i);
+            float ss = 0.f;
+            if (m < p.M && n < p.N) {
+                if (p.bias) v += *(const f32x4*)(p.bias + n);
+                float* x = (float*)p.C + (int64_t)m * p.ldc + n;
+                const f32x4 o = *(f32x4*)x + p.alpha * v;
+                *(f32x4*)x = o;
+                act_store4<bf16_t>(p.nrm_xn, m, n, p.N, o * *(const f32x4*)(p.nrm_w + n));
+                ss = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
+            }
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            if (fg == 0 && (nt0 + t) * 16 < p.N) p.rs_out[(int64_t)m * (p.N >> 4) + (nt0 + t)] = ss;
         }
     } else {
         for (int e = wave; e < NTW * MT; e += NTW * ksplit) {
             const int t = e / MT, i = e - t * MT;
-            epilogue4<EPI, OutT>(p, 16 * i + fr, (nt0 + t) * 16 + 4 * fg, ksum(t, i));
+            epilogue4<EPI, OutT>(p, 16 * i + fr, (nt0 + t) * 16 + 4 * fg, ksum(t, i),
+                                 EPI == EPI_STORE ? deferred_rstd(p, 16 * i + fr) : 1.0f);
         }
     }
 }
@@ -672,6 +727,9 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
     const int my_steps = q + (kw < rr ? 1 : 0);
     const int ks0 = kw * q + (kw < rr ? kw : rr);
     const int64_t tile_stride = (int64_t)nks * 512;  // elements between consecutive 16-row weight tiles
+    // deferred RMSNorm: the scale of the rows this wave's epilogue elements belong to, fetched under the weight stream
+    const int i_pre = kw % MT;
+    const float rstd_pre = (EPI == EPI_SWIGLU || EPI == EPI_STORE) ? deferred_rstd(p, 16 * i_pre + fr) : 1.0f;
 
     const bf16_t* wp = (const bf16_t*)p.W + (((int64_t)nt0 * nks + ks0) * 64 + lane) * 8;
     const bf16_t* xp = (const bf16_t*)p.A + ((int64_t)ks0 * 64 + lane) * 8;
@@ -738,12 +796,14 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
         for (int e = kw; e < (NTB / 2) * MT; e += ksplit) {
             const int j = e / MT, i = e - j * MT;
             const int f = ((nt0 >> 1) + j) * 16 + 4 * fg;
-            epilogue_swiglu4<OutT>(p, 16 * i + fr, f, ksum(2 * j, i), ksum(2 * j + 1, i));
+            epilogue_swiglu4<OutT>(p, 16 * i + fr, f, ksum(2 * j, i), ksum(2 * j + 1, i),
+                                   i == i_pre ? rstd_pre : deferred_rstd(p, 16 * i + fr));
         }
     } else {
         for (int e = kw; e < NTB * MT; e += ksplit) {
             const int t = e / MT, i = e - t * MT;
-            epilogue4<EPI, OutT>(p, 16 * i + fr, (nt0 + t) * 16 + 4 * fg, ksum(t, i));
+            epilogue4<EPI, OutT>(p, 16 * i + fr, (nt0 + t) * 16 + 4 * fg, ksum(t, i),
+                                 EPI != EPI_STORE ? 1.0f : (i == i_pre ? rstd_pre : deferred_rstd(p, 16 * i + fr)));
         }
     }
 }
@@ -758,6 +818,15 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
     const int U = MT <= 2 ? 4 : 2;                       // register budget: (1+MT)*U*2 fragments
     const int nblocks = cdiv(cdiv(a.N, 16), NTW);        // weight rows are padded to 128: all tiles exist
     const int KS = (EPI == EPI_RESID && a.sk_part && a.sk_slices > 1) ? a.sk_slices : 1;
+    if (EPI == EPI_RESID && a.m_split && a.rs_out && NTW == 1) {
+        // deferred-norm residual projection: one workgroup per (weight tile, 16-row activation tile), all of K each
+        int ks = 16;
+        while (ks > 1 && (a.K >> 5) / ks < 4) ks >>= 1;
+        if (a.K % 32 != 0) return false;
+        hipLaunchKernelGGL((gemm_skinny_bf16_kernel<1, NTW, 4, EPI, OutT>), dim3(nblocks, cdiv(a.M, 16)), dim3(NTW * ks * 64),
+                           (size_t)NTW * ks * 64 * 16, st, a);
+        return true;
+    }
     // waves per launch: enough to cover HBM latency on every CU (~2-4 thousand), not more — extra K slices only
     // shorten each wave's stream below the depth of its two-block pipeline (r01 sweeps: LM head, W1)
     int ksplit = 16;

@@ -241,7 +241,7 @@ extern "C" void nvl_destroy(nvl_model* m) {
     dfree(m->x); dfree(m->xn); dfree(m->qkv); dfree(m->q); dfree(m->attn_out); dfree(m->hbuf); dfree(m->h2);
     dfree(m->xn_last); dfree(m->logits); dfree(m->argmax_dev); dfree(m->argmax_pval); dfree(m->argmax_pidx); dfree(m->router_logits); dfree(m->expert_ids);
     dfree(m->expert_w); dfree(m->seg_start); dfree(m->moe_counts); dfree(m->moe_cursor); dfree(m->moe_tile_map); dfree(m->moe_n_mtiles); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo);
-    dfree(m->meta_dev); dfree(m->hidden); dfree(m->sk_part); dfree(m->tp_part); dfree(m->ring);
+    dfree(m->meta_dev); dfree(m->hidden); dfree(m->sk_part); dfree(m->tp_part); dfree(m->ring); dfree(m->rs_part);
     free_sample_bufs(m->samp);
     if (m->tp_comm) (void)ncclCommDestroy((ncclComm_t)m->tp_comm);
     if (m->tp_local) {
@@ -647,6 +647,7 @@ extern "C" int nvl_finalize(nvl_model* m) {
         m->moe_eo = dmalloc<float>(Mmax * k * H);
     }
     if (!m->f32) m->sk_part = dmalloc<float>((int64_t)m->sk_max_slices * 64 * H);
+    if (!m->f32) m->rs_part = dmalloc<float>((int64_t)cdiv(H, 16) * 64);
     if (m->tp > 1 || m->tp_force) m->tp_part = dmalloc<float>(Mmax * H);
     m->meta_ints = 3 * Mmax + 5 * S + m->table_cap + 16;
     NVL_HIP(hipHostMalloc((void**)&m->meta_host, (size_t)m->meta_ints * 4, hipHostMallocDefault));
@@ -852,7 +853,7 @@ GemmArgs mk(const void* A, int lda, const void* W, void* C, int ldc, const float
     a.M = M; a.N = N; a.K = K; a.seg = nullptr; a.c_row0 = 0;
     a.qkv = QkvEpi{};
     a.tile_map = nullptr; a.n_mtiles = nullptr; a.w_expert_stride = 0;
-    a.sk_part = nullptr; a.sk_slices = 1;
+    a.sk_part = nullptr; a.sk_slices = 1; a.m_split = 0; a.nrm_w = nullptr; a.nrm_xn = nullptr; a.rs_out = nullptr; a.rs_in = nullptr; a.rs_tiles = 0; a.rs_inv_h = 0.f; a.rs_eps = 0.f;
     return a;
 }
 
@@ -893,8 +894,14 @@ void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
 // Prefill and the fp32 mode fuse the add into the GEMM epilogue.  Decode-sized batches split K over
 // `slices` workgroups per column block so that all 256 CUs stream weights (a 2048-column projection has
 // only 128 column blocks), and leave the add to the norm kernel that always follows (PendingResid).
+static int g_defer_norm = 1;   // nvl_set_tuning key 3: deferred RMSNorm between O-proj and FFN-up in decode (0 = off)
 static int g_sk_slices = 0;    // tuning override (nvl_set_tuning key 1): 0 automatic, 1 = never split
-void resid_gemm(nvl_model* m, const void* A, int lda, const void* W, const float* bias, float alpha, int M, int N, int K) {
+// consumer side of the deferred RMSNorm: the projection reads xn_raw and scales its accumulators (gemm.h)
+void set_deferred_in(nvl_model* m, GemmArgs& a) {
+    a.rs_in = m->rs_part; a.rs_tiles = m->H / 16; a.rs_inv_h = 1.0f / (float)m->H; a.rs_eps = m->cfg.norm_eps;
+}
+void resid_gemm(nvl_model* m, const void* A, int lda, const void* W, const float* bias, float alpha, int M, int N, int K,
+                const float* defer_norm_w = nullptr) {
     if (m->tp > 1 || m->tp_force) {
         // row-parallel projection: this rank holds a K slice -> fp32 partial [M][N] (the bias lives on rank 0 only),
         // all-reduce over the tensor-parallel group, then the residual add (folded into the next norm for decode)
@@ -911,6 +918,11 @@ void resid_gemm(nvl_model* m, const void* A, int lda, const void* W, const float
         return;
     }
     GemmArgs a = mk(A, lda, W, m->x, N, bias, alpha, M, N, K);
+    if (defer_norm_w) {     // deferred RMSNorm: x complete in this launch (no K split over workgroups) + xn_raw + x^2 partials
+        a.nrm_w = defer_norm_w; a.nrm_xn = (bf16_t*)m->xn; a.rs_out = m->rs_part; a.m_split = g_defer_norm >= 2 ? 0 : 1;
+        gemm(m, EPI_RESID, true, a);
+        return;
+    }
     int slices = 1;
     if (!m->f32 && M <= 64 && !m->keep_hidden && m->sk_part && m->pending_slices == 0 && N % 16 == 0) {
         const int nblocks = N / 16;
@@ -928,7 +940,7 @@ void resid_gemm(nvl_model* m, const void* A, int lda, const void* W, const float
 
 // FeedForward.Forward (transformer.go:40-96) up to (not including) the W2 projection:
 // leaves act(x·W1) in m->hbuf [M][F]
-void ffn_up(nvl_model* m, const LayerW& l, int M) {
+void ffn_up(nvl_model* m, const LayerW& l, int M, bool deferred_norm = false) {
     const bool swiglu = m->cfg.activation_type == NVL_ACT_SWIGLU;
     const float* b1 = (const float*)l.t[NVL_T_B1].p;
     if (swiglu) {
@@ -940,7 +952,9 @@ void ffn_up(nvl_model* m, const LayerW& l, int M) {
                                (float*)m->hbuf, (int64_t)M, m->F);
             NVL_HIP(hipGetLastError());
         } else {
-            gemm(m, EPI_SWIGLU, false, mk(m->xn, m->H, l.w1, m->hbuf, m->F, nullptr, 1.f, M, 2 * m->F, m->H));
+            GemmArgs a = mk(m->xn, m->H, l.w1, m->hbuf, m->F, nullptr, 1.f, M, 2 * m->F, m->H);
+            if (deferred_norm) set_deferred_in(m, a);
+            gemm(m, EPI_SWIGLU, false, a);
         }
     } else {
         gemm(m, EPI_GELU, false, mk(m->xn, m->H, l.w1, m->hbuf, m->F, b1, 1.f, M, m->F, m->H));
@@ -1039,9 +1053,18 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
     const int qw = m->nH * m->hd;
     const bool parallel = c.block_style == NVL_BLOCK_PARALLEL;
 
+    // decode, RMSNorm + SwiGLU, sequential block: every residual projection carries the norm that follows it (deferred
+    // RMSNorm, gemm.h), so a step keeps ONE norm launch (layer 0's, after the embedding) instead of 2L + 1
+    const bool defer_ok = g_defer_norm && !m->f32 && M <= 64 && !c.use_moe && m->tp == 1 && !m->tp_force && !m->keep_hidden &&
+                          c.block_style == NVL_BLOCK_SEQUENTIAL && c.norm_type == NVL_NORM_RMS &&
+                          c.activation_type == NVL_ACT_SWIGLU && H % 256 == 0 && m->rs_part;
+    const bool all_rows = (flags & NVL_FWD_ALL_LOGITS) != 0;
+    bool xn_deferred = false;       // m->xn holds xn_raw of the upcoming norm, m->rs_part its x^2 partials
     for (int li = 0; li < m->L; li++) {
         const LayerW& l = m->layers[li];
-        norm(m, m->x, nullptr, l.t[NVL_T_ATTN_NORM_W], l.t[NVL_T_ATTN_NORM_B], m->xn, M);
+        const bool qkv_deferred = xn_deferred;
+        if (!xn_deferred) norm(m, m->x, nullptr, l.t[NVL_T_ATTN_NORM_W], l.t[NVL_T_ATTN_NORM_B], m->xn, M);
+        xn_deferred = false;
         bool fused_dec = false;
         if (!m->f32 && M > 64) {
             // prefill: RoPE + Q/K/V placement fused into the projection's epilogue (no fp32 qkv round trip)
@@ -1053,7 +1076,9 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
             a.qkv.slot_stride = m->slot_stride; a.qkv.Tmax = m->Tmax; a.qkv.nH = m->nH; a.qkv.nKV = m->nKV; a.qkv.hd = m->hd;
             gemm(m, EPI_QKV, false, a);
         } else {
-            gemm(m, EPI_STORE, true, mk(m->xn, H, l.w_qkv, m->qkv, m->n_qkv, l.b_qkv, 1.f, M, m->n_qkv, H));
+            GemmArgs aq = mk(m->xn, H, l.w_qkv, m->qkv, m->n_qkv, l.b_qkv, 1.f, M, m->n_qkv, H);
+            if (qkv_deferred) set_deferred_in(m, aq);
+            gemm(m, EPI_STORE, true, aq);
             fused_dec = !m->f32 && max_len == 1 && m->group <= 16;     // decode: RoPE + KV append live in the attention kernel
             if (!fused_dec) rope_kv(m, li, md, M);
         }
@@ -1067,13 +1092,27 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
             resid_gemm(m, m->hbuf, m->F, l.t[NVL_T_W2].p, (const float*)l.t[NVL_T_B2].p, mults ? c.residual_multiplier : 1.f,
                        M, H, m->F);   // (only one of the two may be pending: the second one adds into x directly)
         } else {
-            resid_gemm(m, m->attn_out, qw, l.t[NVL_T_WO].p, bo, m->resid_alpha, M, H, qw);
-            norm(m, m->x, nullptr, l.t[NVL_T_FFN_NORM_W], l.t[NVL_T_FFN_NORM_B], m->xn, M);
+            // decode, RMSNorm + SwiGLU: the O-projection carries the FFN norm (deferred RMSNorm, gemm.h) — one launch less
+            const bool defer = defer_ok && m->pending_slices == 0 && !l.t[NVL_T_FFN_NORM_B].present();
+            if (defer) {
+                resid_gemm(m, m->attn_out, qw, l.t[NVL_T_WO].p, bo, m->resid_alpha, M, H, qw, (const float*)l.t[NVL_T_FFN_NORM_W].p);
+            } else {
+                resid_gemm(m, m->attn_out, qw, l.t[NVL_T_WO].p, bo, m->resid_alpha, M, H, qw);
+                norm(m, m->x, nullptr, l.t[NVL_T_FFN_NORM_W], l.t[NVL_T_FFN_NORM_B], m->xn, M);
+            }
             if (c.use_moe) {
                 moe(m, l, M);
             } else {
-                ffn_up(m, l, M);
-                resid_gemm(m, m->hbuf, m->F, l.t[NVL_T_W2].p, (const float*)l.t[NVL_T_B2].p, m->resid_alpha, M, H, m->F);
+                ffn_up(m, l, M, defer);
+                // the FFN-down projection carries the NEXT layer's attention norm, or the final norm when every row is
+                // a last row (decode)
+                const DevTensor* nxt_w = li + 1 < m->L ? &m->layers[li + 1].t[NVL_T_ATTN_NORM_W] : &m->g[NVL_T_FINAL_NORM_W];
+                const DevTensor* nxt_b = li + 1 < m->L ? &m->layers[li + 1].t[NVL_T_ATTN_NORM_B] : &m->g[NVL_T_FINAL_NORM_B];
+                const bool defer2 = defer_ok && g_defer_norm != 3 && m->pending_slices == 0 && !nxt_b->present() &&
+                                    (li + 1 < m->L || (!all_rows && M == n_seqs));
+                resid_gemm(m, m->hbuf, m->F, l.t[NVL_T_W2].p, (const float*)l.t[NVL_T_B2].p, m->resid_alpha, M, H, m->F,
+                           defer2 ? (const float*)nxt_w->p : nullptr);
+                xn_deferred = defer2;
             }
         }
         if (m->keep_hidden)
@@ -1090,9 +1129,15 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
         NVL_HIP(hipMemsetAsync(m->xn_last, 0, (size_t)(round_up(rows, 64) * H) * m->wsize, m->stream));
         m->logit_rows = rows;
     }
-    norm(m, m->x, all ? nullptr : md.last_rows, m->g[NVL_T_FINAL_NORM_W], m->g[NVL_T_FINAL_NORM_B], m->xn_last, rows);
-    if (m->pending_slices != 0) throw std::runtime_error("forward: a split-K residual was left unconsumed");
-    gemm(m, EPI_STORE, true, mk(m->xn_last, H, m->lm_head, m->logits, m->Vpad, nullptr, 1.f, rows, m->V, H));
+    if (xn_deferred) {       // the last FFN-down projection already produced the final norm's operand for every row
+        GemmArgs al = mk(m->xn, H, m->lm_head, m->logits, m->Vpad, nullptr, 1.f, rows, m->V, H);
+        set_deferred_in(m, al);
+        gemm(m, EPI_STORE, true, al);
+    } else {
+        norm(m, m->x, all ? nullptr : md.last_rows, m->g[NVL_T_FINAL_NORM_W], m->g[NVL_T_FINAL_NORM_B], m->xn_last, rows);
+        if (m->pending_slices != 0) throw std::runtime_error("forward: a split-K residual was left unconsumed");
+        gemm(m, EPI_STORE, true, mk(m->xn_last, H, m->lm_head, m->logits, m->Vpad, nullptr, 1.f, rows, m->V, H));
+    }
     {
         KScope ks(m, KC_OTHER);
         launch_argmax(m->stream, m->logits, m->Vpad, m->V, rows, c.logits_scaling, m->argmax_pval, m->argmax_pidx,
