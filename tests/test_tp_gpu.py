@@ -92,8 +92,17 @@ def test_rccl_single_rank_communicator(gpu):
     a = ref.forward_with_cache(toks, 1, 0)
     b = one.forward_with_cache(toks, 1, 0)             # O / W2 go through partial + ncclAllReduce + residual add
     assert rel_err(b, a) <= 1e-5
-    a = ref.forward_with_cache([5], 1, 70, all_logits=False)
+    # decode: the un-sharded model would take the deferred-RMSNorm path (bf16(x*w) instead of bf16(x*w/rms): a bf16-level
+    # difference), the sharded one cannot — switch it off for the tight identity check, then check the tolerance with it on
+    old = gpu.lib().nvl_set_tuning(3, 0)
+    try:
+        a = ref.forward_with_cache([5], 1, 70, all_logits=False)
+    finally:
+        gpu.lib().nvl_set_tuning(3, old)
     b = one.forward_with_cache([5], 1, 70, all_logits=False)
     assert rel_err(b, a) <= 1e-5
+    a2 = ref.forward_with_cache([7], 1, 71, all_logits=False)
+    b2 = one.forward_with_cache([7], 1, 71, all_logits=False)
+    assert rel_err(b2, a2) <= 1.5e-2
     ref.close()
     one.close()
