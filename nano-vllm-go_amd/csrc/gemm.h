@@ -533,6 +533,10 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     // K/32 k-steps dealt over (gridDim.y slices) x (ksplit waves) as evenly as possible (K need not divide:
     // Falcon's 4544 = 142 steps)
     const int i_off = p.m_split ? blockIdx.y : 0;                  // first 16-row activation tile of this workgroup
+    // deferred RMSNorm (consumer side): the scale of the rows of this wave's first epilogue element, fetched under the
+    // weight stream instead of after it
+    const int i_pre = wave % MT;
+    const float rstd_pre = (EPI == EPI_STORE || EPI == EPI_SWIGLU) ? deferred_rstd(p, 16 * i_pre + fr) : 1.0f;
     const int nslices = p.m_split ? 1 : gridDim.y, slice = p.m_split ? 0 : blockIdx.y;
     const int nparts = ksplit * nslices, part = slice * ksplit + kw;
     const int nks = p.K >> 5, q = nks / nparts, rr = nks - q * nparts;
@@ -595,7 +599,8 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     if (EPI == EPI_SWIGLU) {
         for (int i = wave; i < MT; i += NTW * ksplit) {
             const int f = (nt0 >> 1) * 16 + 4 * fg;    // NTW == 2: tiles [gate 16 | up 16] of features 8*nt0..
-            epilogue_swiglu4<OutT>(p, 16 * i + fr, f, ksum(0, i), ksum(NTW - 1, i), deferred_rstd(p, 16 * i + fr));
+            epilogue_swiglu4<OutT>(p, 16 * i + fr, f, ksum(0, i), ksum(NTW - 1, i),
+                                   i == i_pre ? rstd_pre : deferred_rstd(p, 16 * i + fr));
         }
     } else if (EPI == EPI_RESID && nslices > 1) {
         // split-K across workgroups: publish the partial tile (slice 0 carries the bias); the following norm
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
         for (int e = wave; e < NTW * MT; e += NTW * ksplit) {
             const int t = e / MT, i = e - t * MT;
             epilogue4<EPI, OutT>(p, 16 * i + fr, (nt0 + t) * 16 + 4 * fg, ksum(t, i),
-                                 EPI == EPI_STORE ? deferred_rstd(p, 16 * i + fr) : 1.0f);
+                                 EPI != EPI_STORE ? 1.0f : (i == i_pre ? rstd_pre : deferred_rstd(p, 16 * i + fr)));
         }
     }
 }
@@ -808,6 +813,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
     }
 }
 
+static int g_wide_ksplit = 0;   // experiment (nvl_set_tuning key 4): K split of the wide form when groups <= 512
 static int g_force_ntw = 0, g_force_ksplit = 0;   // tuning overrides (nvl_bench_gemm only)
 static int g_force_tile = 0;                      // 0 automatic, 1: 128x128x2st, 2: 256x128x3st, 3: 256x256x2st
 
@@ -848,11 +854,12 @@ static inline bool launch_gemm_skinny_wide(hipStream_t st, const GemmArgs& a) {
     const int groups = cdiv(cdiv(a.N, 16), NTB);     // weight rows are padded to 256: every tile of a group exists
     const int MT = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
     const int U = MT <= 2 ? 4 : 2;
-    // ~1024 waves per launch (one 256-VGPR wave per SIMD, each with up to 32 KiB of weights in flight) stream best:
-    // longer per-wave K slices beat more waves (r01 probe: FFN-up ksplit 4, LM head and the 8B FFN-up ksplit 2)
+    // ~512 waves per launch (256-VGPR waves, each with up to 32 KiB of weights in flight) stream best from HBM: longer
+    // per-wave K slices beat more waves (in the model, weights cold: FFN-up ksplit 2 > 4 > 8 > 1; LM head, 8B FFN-up 2)
     int ksplit = 8;
     if (g_force_ksplit) ksplit = g_force_ksplit <= 8 ? g_force_ksplit : 8;
-    else while (ksplit > 2 && groups * ksplit > 1024) ksplit >>= 1;
+    else if (g_wide_ksplit && groups <= 512) ksplit = g_wide_ksplit;
+    else while (ksplit > 2 && groups * ksplit > 512) ksplit >>= 1;
     while (ksplit > 1 && (a.K >> 5) / ksplit < U) ksplit >>= 1;
     const size_t lds = (size_t)ksplit * NTB * MT * 64 * 16;
 #define NVL_SKW(MTv, Uv)                                                                                               \
