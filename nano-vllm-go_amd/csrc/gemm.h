@@ -813,6 +813,9 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
     }
 }
 
+static int g_msplit_ks = 8;         // K split of the deferred-norm residual projections (nvl_set_tuning key 6)
+static int g_narrow_waves = 1024;   // waves per narrow-form launch (nvl_set_tuning key 5); in the model (weights cold from HBM) fewer,
+                                    // longer per-wave streams win: B=8 +8 %, B=16 +8 %, B=32 +3 % decode vs 4096
 static int g_wide_ksplit = 0;   // experiment (nvl_set_tuning key 4): K split of the wide form when groups <= 512
 static int g_force_ntw = 0, g_force_ksplit = 0;   // tuning overrides (nvl_bench_gemm only)
 static int g_force_tile = 0;                      // 0 automatic, 1: 128x128x2st, 2: 256x128x3st, 3: 256x256x2st
@@ -826,7 +829,7 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
     const int KS = (EPI == EPI_RESID && a.sk_part && a.sk_slices > 1) ? a.sk_slices : 1;
     if (EPI == EPI_RESID && a.m_split && a.rs_out && NTW == 1) {
         // deferred-norm residual projection: one workgroup per (weight tile, 16-row activation tile), all of K each
-        int ks = 16;
+        int ks = g_msplit_ks;
         while (ks > 1 && (a.K >> 5) / ks < 4) ks >>= 1;
         if (a.K % 32 != 0) return false;
         hipLaunchKernelGGL((gemm_skinny_bf16_kernel<1, NTW, 4, EPI, OutT>), dim3(nblocks, cdiv(a.M, 16)), dim3(NTW * ks * 64),
@@ -837,7 +840,7 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
     // shorten each wave's stream below the depth of its two-block pipeline (r01 sweeps: LM head, W1)
     int ksplit = 16;
     if (g_force_ksplit) ksplit = g_force_ksplit;
-    else while (ksplit > 1 && (int64_t)nblocks * KS * NTW * ksplit > 4096) ksplit >>= 1;
+    else while (ksplit > 1 && (int64_t)nblocks * KS * NTW * ksplit > g_narrow_waves) ksplit >>= 1;
     while (ksplit > 1 && ((a.K >> 5) / (ksplit * KS) < U || ksplit * NTW > 16)) ksplit >>= 1;   // >= one block of U k-steps per wave
     if (a.K % 32 != 0) return false;
     const size_t lds = (size_t)NTW * ksplit * MT * 64 * 16;

@@ -386,6 +386,8 @@ extern "C" int nvl_bench_gemm(int device, int M, int N, int K, int epi, int forc
 extern "C" int nvl_set_tuning(int key, int value) {
     if (key == 0) { const int old = g_force_tile; g_force_tile = value; return old; }
     if (key == 1) { const int old = g_sk_slices; g_sk_slices = value; return old; }
+    if (key == 6) { const int old = g_msplit_ks; g_msplit_ks = value; return old; }
+    if (key == 5) { const int old = g_narrow_waves; g_narrow_waves = value; return old; }
     if (key == 4) { const int old = g_wide_ksplit; g_wide_ksplit = value; return old; }
     if (key == 3) { const int old = g_defer_norm; g_defer_norm = value; return old; }
     if (key == 2) { const int old = g_force_ntw; g_force_ntw = value; return old; }
