@@ -338,7 +338,9 @@ int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int 
  * key 1: K slices of the decode residual projections (0 automatic, 1 never split, 2, 4).
  * key 2: decode (M <= 64) GEMM form: 0 automatic, 1/2/4 = narrow form with that many weight tiles per workgroup,
  * 8 = wide-N form (4 weight tiles per wave).
- * key 3: deferred RMSNorm between the decode O-projection and FFN-up (1 on, 0 off).  Returns the previous value. */
+ * key 3: deferred RMSNorm in decode (0 off, 1 on, 2 on without the activation-tile split, 3 only the O-proj -> FFN-up seam).
+ * keys 4-6 (sweeps): K split of the wide form, waves per narrow-form launch, K split of the deferred-norm residual
+ * projections.  Returns the previous value. */
 int nvl_set_tuning(int key, int value);
 
 #ifdef __cplusplus
