@@ -536,7 +536,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     // deferred RMSNorm (consumer side): the scale of the rows of this wave's first epilogue element, fetched under the
     // weight stream instead of after it
     const int i_pre = wave % MT;
-    const float rstd_pre = (EPI == EPI_STORE || EPI == EPI_SWIGLU) ? deferred_rstd(p, 16 * i_pre + fr) : 1.0f;
+    const float rstd_pre = ((EPI == EPI_STORE || EPI == EPI_SWIGLU) && wave < NTW * MT) ? deferred_rstd(p, 16 * i_pre + fr) : 1.0f;   // (only the waves that run an epilogue element)
     const int nslices = p.m_split ? 1 : gridDim.y, slice = p.m_split ? 0 : blockIdx.y;
     const int nparts = ksplit * nslices, part = slice * ksplit + kw;
     const int nks = p.K >> 5, q = nks / nparts, rr = nks - q * nparts;
@@ -862,7 +862,7 @@ static inline bool launch_gemm_skinny_wide(hipStream_t st, const GemmArgs& a) {
     int ksplit = 8;
     if (g_force_ksplit) ksplit = g_force_ksplit <= 8 ? g_force_ksplit : 8;
     else if (g_wide_ksplit && groups <= 512) ksplit = g_wide_ksplit;
-    else while (ksplit > 2 && groups * ksplit > 512) ksplit >>= 1;
+    else { while (ksplit > 2 && groups * ksplit > 512) ksplit >>= 1; if (groups >= 1024) ksplit = 1; }   // LM head: one wave per group (cold sweep: 96 vs 104 us)
     while (ksplit > 1 && (a.K >> 5) / ksplit < U) ksplit >>= 1;
     const size_t lds = (size_t)ksplit * NTB * MT * 64 * 16;
 #define NVL_SKW(MTv, Uv)                                                                                               \
