@@ -508,6 +508,133 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pipe_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 MFMA kernel, ping-pong form (prefill, tuning option 5): 256x256 tile, 8 waves as two groups of four (one wave
+// of each group per SIMD), K in 32-wide stages through a 5-slot LDS ring (160 KiB).  A stage is one PHASE for a wave:
+//   L: 12 fragment ds_reads of stage s, LDS-DMA issue of stage s+4, lgkmcnt(0), counted vmcnt (stage s+1 landed)
+//   -- barrier --   C: 32 MFMAs at priority 1   -- barrier --
+// Group 1 enters the loop one barrier late, so while one wave of a SIMD issues its MFMAs the other does its LDS reads
+// and DMA issue: the fragment reads (384 of every 896 cycles in the lock-step kernel above) move under the MFMAs.
+// Hazards (LDS-DMA is ordered only by the issuer's vmcnt + a barrier the reader passes): a slot is re-filled in L(s)
+// after its last readers retired their ds_reads before the barrier that ended L(s-1) of the LATE group (WAR);
+// stage s+1 is waited for at the end of L(s) by every wave, one barrier before the early group reads it (RAW).
+// ------------------------------------------------------------------------------------------
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 256, WAVES_N = 4, TM = 8, TN = 4, STAGES = 5;
+    constexpr int NA = BM / 16, NB = BN / 16;            // 1-KiB blocks per stage (one k-step)
+    constexpr int PW = (NA + NB) / 8;                    // 4 blocks per wave per stage
+    constexpr int STAGE_BYTES = (BM + BN) * 32 * 2;      // 32 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (p.N + BN - 1) / BN;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), gridDim.x / tiles_n, tiles_n, 4, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;   // wm = the ping-pong group
+    const int fr = lane & 15, fg = lane >> 4;
+    if (m0 >= p.M) return;
+
+    const bf16_t* src[PW];
+#pragma unroll
+    for (int i = 0; i < PW; i++) {
+        const int blk = wave * PW + i;
+        if (blk < NA) {
+            int am = m0 + blk * 16 + fr;
+            if (am > p.M - 1) am = p.M - 1;
+            src[i] = (const bf16_t*)p.A + (((int64_t)(am >> 4) * (p.K >> 5) * 64) + (am & 15) + 16 * fg) * 8;
+        } else {
+            src[i] = (const bf16_t*)p.W + ((int64_t)((n0 >> 4) + blk - NA) * (p.K >> 5) * 64 + lane) * 8;
+        }
+    }
+    auto stage = [&](int buf, int ks) {
+        char* base = smem + buf * STAGE_BYTES + wave * (PW * 1024);
+#pragma unroll
+        for (int i = 0; i < PW; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)ks * 512),
+                                             (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+    };
+    const int a_off = wm * TM * 1024 + lane * 16;
+    const int w_off = NA * 1024 + wn * TN * 1024 + lane * 16;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = p.K >> 5;            // stages
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; s++)
+        if (s < nt) stage(s, s);
+    // stage 0 landed (my part); up to three younger stages stay in flight
+    if (nt >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (nt == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nt == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();          // the late group: one phase behind from here on
+    int buf = 0;
+    for (int s = 0; s < nt; s++) {
+        // ---- L phase ----
+        bf16x8 af[TM], wf[TN];
+        const char* sbuf = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < TN; j++) wf[j] = *(const bf16x8*)(sbuf + w_off + j * 1024);
+#pragma unroll
+        for (int i = 0; i < TM; i++) af[i] = *(const bf16x8*)(sbuf + a_off + i * 1024);
+        if (s + STAGES - 1 < nt) {
+            int nb = buf + STAGES - 1;                   // the slot read in phase s-1
+            if (nb >= STAGES) nb -= STAGES;
+            stage(nb, s + STAGES - 1);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): my fragment reads are retired
+        // stage s+1 landed; stages s+2 .. s+4 (those that exist) may stay in flight
+        {
+            const int younger = nt - 2 - s;              // stages beyond s+1
+            if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- C phase ----
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();          // pairs with the late group's last barrier
+
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int m = m0 + wm * (TM * 16) + i * 16 + fr;
+        if (EPI == EPI_QKV) {
+            const int head = (n0 + wn * 64) >> 6;
+            if (head * 64 < p.N) epilogue_qkv_head<4>(p, m, head, fg, acc[i]);
+        } else if (EPI == EPI_SWIGLU) {
+#pragma unroll
+            for (int j = 0; j < TN; j += 2) {
+                const int ntile = (n0 + wn * (TN * 16) + j * 16) >> 4;
+                epilogue_swiglu4<OutT>(p, m, (ntile >> 1) * 16 + 4 * fg, acc[i][j], acc[i][j + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                epilogue4<EPI, OutT>(p, m, n0 + wn * (TN * 16) + j * 16 + 4 * fg, acc[i][j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // bf16 skinny kernel (decode: M <= 64 rows).  The projection is then a weight-streaming problem
 // (HBM-bound: every weight byte is read once, activations are a few hundred KB in L2), so the
 // shape of the kernel is set by memory-level parallelism, not by MFMA:
@@ -943,7 +1070,7 @@ static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
         tile = 1;
         if (!a.seg && a.K >= 128) {
             const int t3 = cdiv(a.M, 256) * cdiv(a.N, 256), t2 = cdiv(a.M, 256) * cdiv(a.N, 128);
-            if (t3 >= 256 && cu_fill(t3, 1) >= 0.74) tile = 3;
+            if (t3 >= 256 && cu_fill(t3, 1) >= 0.74) tile = (!a.seg && !a.a_rows && a.K >= 160) ? 5 : 3;   // 5: ping-pong form
             else if (t2 >= 256 && cu_fill(t2, 1) >= 0.74) tile = 2;
         }
     }
@@ -956,6 +1083,17 @@ static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
         }
         hipLaunchKernelGGL((gemm_bf16_pipe_kernel<EPI, OutT>), dim3(cdiv(a.M, 256) * cdiv(a.N, 256)), dim3(512),
                            128 * 1024, st, a);
+        return;
+    }
+    if (tile == 5 && !a.seg && !a.a_rows) {
+        static bool attr5 = false;
+        if (!attr5) {
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI, OutT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr5 = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, OutT>), dim3(cdiv(a.M, 256) * cdiv(a.N, 256)), dim3(512),
+                           160 * 1024, st, a);
         return;
     }
     if (tile == 3) launch_gemm_tile<256, 256, 2, 4, 2, EPI, OutT>(st, a);
