@@ -509,8 +509,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pipe_kernel(GemmArgs p) {
 
 // ------------------------------------------------------------------------------------------
 // bf16 MFMA kernel, ping-pong form (prefill, tuning option 5): 256x256 tile, 8 waves as two groups of four (one wave
-// of each group per SIMD), K in 32-wide stages through a 5-slot LDS ring (160 KiB).  A stage is one PHASE for a wave:
-//   L: 12 fragment ds_reads of stage s, LDS-DMA issue of stage s+4, lgkmcnt(0), counted vmcnt (stage s+1 landed)
+// of each group per SIMD), K in 32-wide stages through a STAGES-slot LDS ring (4 slots = 128 KiB by default).  A stage is one PHASE for a wave:
+//   L: 12 fragment ds_reads of stage s, LDS-DMA issue of stage s+STAGES-1, lgkmcnt(0), counted vmcnt (stage s+1 landed)
 //   -- barrier --   C: 32 MFMAs at priority 1   -- barrier --
 // Group 1 enters the loop one barrier late, so while one wave of a SIMD issues its MFMAs the other does its LDS reads
 // and DMA issue: the fragment reads (384 of every 896 cycles in the lock-step kernel above) move under the MFMAs.
@@ -518,9 +518,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pipe_kernel(GemmArgs p) {
 // after its last readers retired their ds_reads before the barrier that ended L(s-1) of the LATE group (WAR);
 // stage s+1 is waited for at the end of L(s) by every wave, one barrier before the early group reads it (RAW).
 // ------------------------------------------------------------------------------------------
-template <int EPI, typename OutT>
+template <int EPI, typename OutT, int STAGES = 4, int PRIO = 0>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmArgs p) {
-    constexpr int BM = 256, BN = 256, WAVES_N = 4, TM = 8, TN = 4, STAGES = 5;
+    constexpr int BM = 256, BN = 256, WAVES_N = 4, TM = 8, TN = 4;
     constexpr int NA = BM / 16, NB = BN / 16;            // 1-KiB blocks per stage (one k-step)
     constexpr int PW = (NA + NB) / 8;                    // 4 blocks per wave per stage
     constexpr int STAGE_BYTES = (BM + BN) * 32 * 2;      // 32 KiB
@@ -566,13 +566,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmArgs p) {
 #pragma unroll
     for (int s = 0; s < STAGES - 1; s++)
         if (s < nt) stage(s, s);
-    // stage 0 landed (my part); up to three younger stages stay in flight
-    if (nt >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (nt == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nt == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // stage 0 landed (my part); up to STAGES-2 younger stages stay in flight
+    auto wait_younger = [&](int younger) {
+        if (younger > STAGES - 2) younger = STAGES - 2;
+        if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    static_assert(STAGES >= 3 && STAGES <= 5, "vmcnt immediates above cover up to three stages in flight");
+    wait_younger((nt < STAGES - 1 ? nt : STAGES - 1) - 1);
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();          // the late group: one phase behind from here on
+    if (PRIO == 1 && wm == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the second-dispatched half
     int buf = 0;
     for (int s = 0; s < nt; s++) {
         // ---- L phase ----
@@ -589,24 +595,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmArgs p) {
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): my fragment reads are retired
         // stage s+1 landed; stages s+2 .. s+4 (those that exist) may stay in flight
-        {
-            const int younger = nt - 2 - s;              // stages beyond s+1
-            if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        wait_younger(nt - 2 - s);                        // (stages beyond s+1 that exist)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- C phase ----
-        __builtin_amdgcn_s_setprio(1);
+        if (PRIO == 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO == 0) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -1085,17 +1085,22 @@ static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
                            128 * 1024, st, a);
         return;
     }
-    if (tile == 5 && !a.seg && !a.a_rows) {
-        static bool attr5 = false;
-        if (!attr5) {
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI, OutT>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr5 = true;
-        }
-        hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, OutT>), dim3(cdiv(a.M, 256) * cdiv(a.N, 256)), dim3(512),
-                           160 * 1024, st, a);
-        return;
+#define NVL_PP(TILE, ST, PR)                                                                                          \
+    if (tile == TILE && !a.seg && !a.a_rows) {                                                                         \
+        static bool attr = false;                                                                                      \
+        if (!attr) {                                                                                                   \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI, OutT, ST, PR>,                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, ST * 32 * 1024);                     \
+            attr = true;                                                                                               \
+        }                                                                                                              \
+        hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, OutT, ST, PR>), dim3(cdiv(a.M, 256) * cdiv(a.N, 256)), dim3(512), \
+                           ST * 32 * 1024, st, a);                                                                     \
+        return;                                                                                                        \
     }
+    NVL_PP(5, 4, 0)      // the default large-M form: 4-slot ring (5 slots: -3 %, 3 slots: -3 %, r01 sweep)
+    NVL_PP(6, 4, 1)      // sweep: static priority for the late group instead of per-phase flips
+    NVL_PP(7, 4, 2)      // sweep: no priority changes
+#undef NVL_PP
     if (tile == 3) launch_gemm_tile<256, 256, 2, 4, 2, EPI, OutT>(st, a);
     else if (tile == 2) launch_gemm_tile<256, 128, 4, 2, 3, EPI, OutT>(st, a);
     else launch_gemm_tile<128, 128, 2, 2, 2, EPI, OutT>(st, a);
