@@ -251,7 +251,7 @@ def main():
     traffic = None
     try:
         if args.model == "llama-3.2-1b" and (B, S) == (32, 512) and args.precision == "bf16":
-            traffic = round(json.load(open(ROOT / "profiles" / "r01c_pmc_traffic.json"))
+            traffic = round(json.load(open(ROOT / "profiles" / "r01e_pmc_traffic.json"))
                             ["prefill_gemm_class_avg_bytes_per_launch"])
     except Exception:
         traffic = None
@@ -266,10 +266,10 @@ def main():
                    "batch_per_gpu": B, "prompt_len": S, "gen_len": G, "parallelism": (f"tp{world} (column/row-parallel, RCCL all-reduce)" if tp else f"dp{world} over sequences")},
         "prefill_tokens_per_s": round(nrep * B * S * args.steps / pre_s, 1),
         "decode_tokens_per_s": round(nrep * B * G * args.steps / dec_s, 1),
-        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (prefill QKV/O/FFN/LM-head projections)",
+        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel (prefill QKV/O/FFN projections; gemm_bf16_kernel for the small LM-head GEMM)",
                      "achieved": round(gemm_tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(gemm_tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-                     "traffic_note": "bytes/launch past L2 (incl. Infinity-Cache hits), profiles/r01c_pmc_traffic.json",
+                     "traffic_note": "bytes/launch past L2 (incl. Infinity-Cache hits), profiles/r01e_pmc_traffic.json",
                      "launches": int(st["gemm_launches"]),
                      "avg_launch_us": round(1e3 * st["gemm_ms"] / max(1, st["gemm_launches"]), 2)},
         "decode_roofline": {"bound": "hbm", "achieved": round(dec_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -15,7 +15,7 @@ fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 out = {}
 tot_b = tot_n = 0
 for k in sorted(fetch):
-    if "gemm_bf16_kernel" not in k: continue
+    if "gemm_bf16_kernel" not in k and "gemm_bf16_pp_kernel" not in k: continue
     f = fetch[k]; w = write.get(k, [0.0])
     per = (2.0 * sum(f) / len(f) + sum(w) / max(1, len(w))) * 1024.0
     out[k] = {"launches": len(f), "fetch_KiB_raw_avg": sum(f) / len(f), "write_KiB_avg": sum(w) / max(1, len(w)),
