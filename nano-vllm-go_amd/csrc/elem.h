@@ -110,35 +110,12 @@ struct PendingResid {
     int rows_total;
     float alpha;
 };
+// the arithmetic of one row once it sits in registers (shared by norm_row_kernel and decode_seam_kernel)
 template <typename ActT>
-__global__ __launch_bounds__(256) void norm_row_kernel(float* __restrict__ x,
-                                                       const int32_t* __restrict__ rows_idx,
-                                                       const float* __restrict__ w,
-                                                       const float* __restrict__ b, float eps,
-                                                       ActT* __restrict__ y, int H, PendingResid pr) {
-    __shared__ float red[4];
-    const int r = blockIdx.x;
-    const int src = rows_idx ? rows_idx[r] : r;
-    float* xr = x + (int64_t)src * H;
+__device__ __forceinline__ void norm_row_finish(f32x4 (&v)[NORM_ROW_MAXCH], f32x4 (&ww)[NORM_ROW_MAXCH],
+                                                f32x4 (&bb)[NORM_ROW_MAXCH], const float* b, float eps, ActT* y, int r,
+                                                int H, float* red) {
     const int H4 = H >> 2;
-    f32x4 v[NORM_ROW_MAXCH], ww[NORM_ROW_MAXCH], bb[NORM_ROW_MAXCH];
-#pragma unroll
-    for (int c = 0; c < NORM_ROW_MAXCH; c++) {
-        const int j = threadIdx.x + c * 256;
-        v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (j < H4) {
-            v[c] = *(const f32x4*)(xr + j * 4);
-            if (pr.part) {
-                f32x4 s = *(const f32x4*)(pr.part + (int64_t)src * H + j * 4);
-                for (int k = 1; k < pr.slices; k++)
-                    s += *(const f32x4*)(pr.part + ((int64_t)k * pr.rows_total + src) * H + j * 4);
-                v[c] += pr.alpha * s;
-                *(f32x4*)(xr + j * 4) = v[c];
-            }
-            ww[c] = *(const f32x4*)(w + j * 4);
-            if (b) bb[c] = *(const f32x4*)(b + j * 4);
-        }
-    }
     if (b == nullptr) {
         float ss = 0.f;
 #pragma unroll
@@ -180,6 +157,38 @@ __global__ __launch_bounds__(256) void norm_row_kernel(float* __restrict__ x,
             }
         }
     }
+}
+
+template <typename ActT>
+__global__ __launch_bounds__(256) void norm_row_kernel(float* __restrict__ x,
+                                                       const int32_t* __restrict__ rows_idx,
+                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ b, float eps,
+                                                       ActT* __restrict__ y, int H, PendingResid pr) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const int src = rows_idx ? rows_idx[r] : r;
+    float* xr = x + (int64_t)src * H;
+    const int H4 = H >> 2;
+    f32x4 v[NORM_ROW_MAXCH], ww[NORM_ROW_MAXCH], bb[NORM_ROW_MAXCH];
+#pragma unroll
+    for (int c = 0; c < NORM_ROW_MAXCH; c++) {
+        const int j = threadIdx.x + c * 256;
+        v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j < H4) {
+            v[c] = *(const f32x4*)(xr + j * 4);
+            if (pr.part) {
+                f32x4 s = *(const f32x4*)(pr.part + (int64_t)src * H + j * 4);
+                for (int k = 1; k < pr.slices; k++)
+                    s += *(const f32x4*)(pr.part + ((int64_t)k * pr.rows_total + src) * H + j * 4);
+                v[c] += pr.alpha * s;
+                *(f32x4*)(xr + j * 4) = v[c];
+            }
+            ww[c] = *(const f32x4*)(w + j * 4);
+            if (b) bb[c] = *(const f32x4*)(b + j * 4);
+        }
+    }
+    norm_row_finish<ActT>(v, ww, bb, b, eps, y, r, H, red);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -329,6 +338,66 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restric
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) argmax_merge(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
     if (threadIdx.x == 0) out[r] = (bi == 0x7fffffff) ? 0 : bi;   // all -inf / NaN: reference returns index 0
+}
+
+// ---------------------------------------------------------------------------------------
+// Decode seam (nvl_decode_greedy, bf16 path): the tail of step s and the head of step s+1 as ONE launch, one
+// 256-thread block per sequence: argmax over the chunk partials (argmax_final_kernel), the token fed back + every
+// position advanced by one (cmd/ask/main.go:315-320), the embedding gather of that token (embed_kernel,
+// generic_model.go:567-592) and layer 0's norm of the row (norm_row_kernel) — same arithmetic, same summation order.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_seam_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
+                                                          int chunks, int32_t* __restrict__ argmax_out,
+                                                          int32_t* __restrict__ ring_out, int32_t* __restrict__ tokens,
+                                                          int32_t* __restrict__ tok_pos, int32_t* __restrict__ seq_pos,
+                                                          const bf16_t* __restrict__ emb, const bf16_t* __restrict__ pos_emb,
+                                                          int max_seq, float mult, float* __restrict__ x,
+                                                          const float* __restrict__ w, const float* __restrict__ b,
+                                                          float eps, bf16_t* __restrict__ y, int H) {
+    __shared__ float red[4];
+    __shared__ int tok_s, pos_s;
+    const int r = blockIdx.x;
+    if (threadIdx.x < 64) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = threadIdx.x; c < chunks; c += 64) argmax_merge(best, bi, pval[r * chunks + c], pidx[r * chunks + c]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) argmax_merge(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
+        if (threadIdx.x == 0) {
+            const int t = (bi == 0x7fffffff) ? 0 : bi;
+            const int pos = tok_pos[r] + 1;
+            argmax_out[r] = t; ring_out[r] = t; tokens[r] = t;
+            tok_pos[r] = pos; seq_pos[r] = pos;          // (one token per sequence: row r IS sequence r)
+            tok_s = t; pos_s = pos;
+        }
+    }
+    __syncthreads();
+    const int tok = tok_s, pos = pos_s;
+    const bool use_pos = pos_emb && pos < max_seq;
+    float* xr = x + (int64_t)r * H;
+    const int H4 = H >> 2;
+    f32x4 v[NORM_ROW_MAXCH], ww[NORM_ROW_MAXCH], bb[NORM_ROW_MAXCH];
+#pragma unroll
+    for (int c = 0; c < NORM_ROW_MAXCH; c++) {
+        const int j = threadIdx.x + c * 256;
+        v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j < H4) {
+            const bf16x4 e = *(const bf16x4*)(emb + fm_index(tok, j * 4, H));
+            bf16x4 pe = {};
+            if (use_pos) pe = *(const bf16x4*)(pos_emb + fm_index(pos, j * 4, H));
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float f = (float)e[k];
+                if (use_pos) f += (float)pe[k];
+                if (mult != 0.f) f *= mult;
+                v[c][k] = f;
+            }
+            *(f32x4*)(xr + j * 4) = v[c];
+            ww[c] = *(const f32x4*)(w + j * 4);
+            if (b) bb[c] = *(const f32x4*)(b + j * 4);
+        }
+    }
+    norm_row_finish<bf16_t>(v, ww, bb, b, eps, y, r, H, red);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -844,7 +844,7 @@ void launch_argmax(hipStream_t st, float* logits, int ld, int V, int rows, float
                    int32_t* out) {
     const int chunks = cdiv(V, ARGMAX_CHUNK);
     hipLaunchKernelGGL(argmax_partial_kernel, dim3(chunks, rows), dim3(256), 0, st, logits, ld, V, scaling, pval, pidx);
-    hipLaunchKernelGGL(argmax_final_kernel, dim3(rows), dim3(64), 0, st, pval, pidx, chunks, out);
+    if (out) hipLaunchKernelGGL(argmax_final_kernel, dim3(rows), dim3(64), 0, st, pval, pidx, chunks, out);
 }
 
 GemmArgs mk(const void* A, int lda, const void* W, void* C, int ldc, const float* bias, float alpha, int M, int N, int K) {
@@ -894,6 +894,7 @@ void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
 // Prefill and the fp32 mode fuse the add into the GEMM epilogue.  Decode-sized batches split K over
 // `slices` workgroups per column block so that all 256 CUs stream weights (a 2048-column projection has
 // only 128 column blocks), and leave the add to the norm kernel that always follows (PendingResid).
+static int g_decode_seam = 1;  // nvl_set_tuning key 7: decode_seam_kernel in nvl_decode_greedy (0 = separate kernels)
 static int g_defer_norm = 1;   // nvl_set_tuning key 3: deferred RMSNorm between O-proj and FFN-up in decode (0 = off)
 static int g_sk_slices = 0;    // tuning override (nvl_set_tuning key 1): 0 automatic, 1 = never split
 // consumer side of the deferred RMSNorm: the projection reads xn_raw and scales its accumulators (gemm.h)
@@ -1025,7 +1026,10 @@ void moe(nvl_model* m, const LayerW& l, int M) {
 namespace {
 // Enqueue ONE forward pass (embedding ... argmax) on the model's stream for the batch described by the device
 // metadata `md` — no host synchronisation.  Returns the number of logits rows produced.
-int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len, double attn_flops, uint32_t flags) {
+// seam: 0 = whole pass; bit 0 = x and layer 0's normed operand are already in place (skip embed + first norm);
+// bit 1 = stop after the argmax partials (the caller's decode_seam_kernel finishes the step)
+int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len, double attn_flops, uint32_t flags,
+                    int seam = 0) {
     const nvl_model_config& c = m->cfg;
     const int H = m->H;
     m->pending_slices = 0;
@@ -1037,7 +1041,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
     m->hidden_last_M = M;
 
     // ---- embed (generic_model.go:295-302) -------------------------------------------------
-    {
+    if (!(seam & 1)) {
         KScope ks(m, KC_OTHER);
         const void* pe = (c.position_type == NVL_POS_LEARNED) ? m->g[NVL_T_POS_EMB].p : nullptr;
         const int pe_rows = pe ? (int)std::min<int64_t>(m->g[NVL_T_POS_EMB].rows, c.max_seq_len) : 0;
@@ -1063,7 +1067,8 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
     for (int li = 0; li < m->L; li++) {
         const LayerW& l = m->layers[li];
         const bool qkv_deferred = xn_deferred;
-        if (!xn_deferred) norm(m, m->x, nullptr, l.t[NVL_T_ATTN_NORM_W], l.t[NVL_T_ATTN_NORM_B], m->xn, M);
+        if (!xn_deferred && !(li == 0 && (seam & 1)))
+            norm(m, m->x, nullptr, l.t[NVL_T_ATTN_NORM_W], l.t[NVL_T_ATTN_NORM_B], m->xn, M);
         xn_deferred = false;
         bool fused_dec = false;
         if (!m->f32 && M > 64) {
@@ -1141,7 +1146,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
     {
         KScope ks(m, KC_OTHER);
         launch_argmax(m->stream, m->logits, m->Vpad, m->V, rows, c.logits_scaling, m->argmax_pval, m->argmax_pidx,
-                      m->argmax_dev);
+                      (seam & 2) ? nullptr : m->argmax_dev);
         NVL_HIP(hipGetLastError());
     }
     m->last_rows = rows;
@@ -1412,9 +1417,23 @@ extern "C" int nvl_decode_greedy(nvl_model* m, int n_seqs, const int64_t* seq_id
     for (int s = 0; s < n_steps; s++) {
         double attn_flops = 0;
         for (int i = 0; i < n_seqs; i++) attn_flops += 4.0 * m->hd * m->nH * (double)(h_pos[i] + s + 1);
-        enqueue_forward(m, md, n_seqs, M, 1, attn_flops, 0);
-        hipLaunchKernelGGL(advance_decode_kernel, dim3(cdiv(n_seqs, 256)), dim3(256), 0, m->stream, m->argmax_dev, md.tokens,
-                           md.tok_pos, md.seq_pos, m->ring + (int64_t)s * n_seqs, n_seqs);
+        // bf16 path: the step's tail (argmax, token feedback) and the next step's head (embedding gather + layer 0's
+        // norm) are one launch (decode_seam_kernel); fp32 parity mode keeps the separate kernels
+        const bool seam_ok = g_decode_seam && !m->f32 && m->H <= 1024 * NORM_ROW_MAXCH && m->H % 4 == 0;
+        enqueue_forward(m, md, n_seqs, M, 1, attn_flops, 0, seam_ok ? ((s > 0 ? 1 : 0) | 2) : 0);
+        if (seam_ok) {
+            const void* pe = (m->cfg.position_type == NVL_POS_LEARNED) ? m->g[NVL_T_POS_EMB].p : nullptr;
+            const int pe_rows = pe ? (int)std::min<int64_t>(m->g[NVL_T_POS_EMB].rows, m->cfg.max_seq_len) : 0;
+            const LayerW& l0 = m->layers[0];
+            hipLaunchKernelGGL(decode_seam_kernel, dim3(n_seqs), dim3(256), 0, m->stream, m->argmax_pval, m->argmax_pidx,
+                               cdiv(m->V, ARGMAX_CHUNK), m->argmax_dev, m->ring + (int64_t)s * n_seqs, md.tokens, md.tok_pos,
+                               md.seq_pos, (const bf16_t*)m->g[NVL_T_TOK_EMB].p, (const bf16_t*)pe, pe_rows,
+                               m->cfg.embedding_multiplier, m->x, (const float*)l0.t[NVL_T_ATTN_NORM_W].p,
+                               (const float*)l0.t[NVL_T_ATTN_NORM_B].p, m->cfg.norm_eps, (bf16_t*)m->xn, m->H);
+        } else {
+            hipLaunchKernelGGL(advance_decode_kernel, dim3(cdiv(n_seqs, 256)), dim3(256), 0, m->stream, m->argmax_dev, md.tokens,
+                               md.tok_pos, md.seq_pos, m->ring + (int64_t)s * n_seqs, n_seqs);
+        }
         NVL_HIP(hipGetLastError());
     }
     m->keep_hidden = dbg;
