@@ -21,7 +21,7 @@ for M in ():
 # prefill shapes
 for name,M,N,K,epi in [("qkv",16384,3072,2048,0),("o",16384,2048,2048,1),("w1",16384,16384,2048,2),("w2",16384,2048,8192,1),("sq4k",4096,4096,4096,0),("sq8k",8192,8192,8192,0)]:
     row = []
-    for tile in (5, 6, 7):
+    for tile in (1, 3, 5):
         us = bench(M,N,K,epi,bnt=tile,iters=10)
         row.append(f"tile{tile}: {us:8.1f} us {2*M*N*K/us/1e6:7.1f} TF/s")
     print(f"prefill {name:5s} M={M} N={N} K={K}: " + "   ".join(row))
