@@ -120,6 +120,20 @@ def test_attention(gpu, oracle, nH, nKV, S, T, precision):
     assert rel_err(got, want) <= (5e-5 if precision == "f32" else BF16_TOL)
 
 
+@pytest.mark.parametrize("nH,nKV,S,T,hd", [(8, 2, 1, 2100, 64),      # decode: > 1024 keys -> the split-T loop runs twice per wave
+                                            (4, 4, 1, 1100, 64), (4, 1, 1, 1500, 128),
+                                            (4, 2, 300, 1400, 64)])  # chunked prefill against a long cache
+def test_attention_long_context(gpu, oracle, nH, nKV, S, T, hd):
+    r = rng(T)
+    q = r.standard_normal((nH, S, hd), dtype=np.float32)
+    k = r.standard_normal((nKV, T, hd), dtype=np.float32)
+    v = r.standard_normal((nKV, T, hd), dtype=np.float32)
+    want = oracle.gqa_core(q, k, v)
+    assert rel_err(gpu.ops.attention(q, k, v, precision="bf16"), want) <= BF16_TOL
+    if S == 1:
+        assert rel_err(gpu.ops.attention(q, k, v, precision="f32"), want) <= 5e-5
+
+
 def test_attention_custom_scale_and_hd128(gpu, oracle):
     r = rng(5)
     q = r.standard_normal((4, 6, 128), dtype=np.float32)
