@@ -334,7 +334,7 @@ int nvl_op_sample(int device, const float* logits, int rows, int V, const nvl_sa
 int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int force_ksplit, int iters,
                    float* avg_us);
 /* Process-wide tuning override used by tests and sweeps.  key 0: prefill GEMM kernel (0 automatic,
- * 1 = 128x128 two-stage, 2 = 256x128 three-stage, 3 = 256x256 two-stage, 4 = 256x256 pipelined).
+ * 1 = 128x128 two-stage, 2 = 256x128 three-stage, 3 = 256x256 two-stage, 5 = 256x256 ping-pong).
  * key 1: K slices of the decode residual projections (0 automatic, 1 never split, 2, 4).
  * key 2: decode (M <= 64) GEMM form: 0 automatic, 1/2/4 = narrow form with that many weight tiles per workgroup,
  * 8 = wide-N form (4 weight tiles per wave).

@@ -392,122 +392,6 @@ void gemm_bf16_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// bf16 MFMA kernel, software-pipelined large-M instance: 256x256 tile, 8 waves (2x4), wave tile
-// 128x64 (8x4 accumulators), K step 32 (one MFMA k-step), FOUR LDS stages of 32 KiB.
-// Three overlapped pipelines per wave:   HBM -> LDS   (global_load_lds, two K steps in flight across the barrier)
-//                                        LDS -> VGPR  (fragment ds_reads of step t+1 issued BEFORE the MFMAs of step t)
-//                                        MFMA         (32 per step on the fragments read during the previous step)
-// so neither the global latency nor the LDS read latency sits in front of the matrix pipe; the one raw
-// s_barrier per step only hands buffers over.  Register sets A/B alternate statically (loop unrolled x2).
-// ------------------------------------------------------------------------------------------
-template <int EPI, typename OutT>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_pipe_kernel(GemmArgs p) {
-    constexpr int BM = 256, BN = 256, WAVES_N = 4, TM = 8, TN = 4, STAGES = 4;
-    constexpr int NA = BM / 16, NB = BN / 16;            // 1-KiB blocks per stage (one k-step)
-    constexpr int PW = (NA + NB) / 8;                    // 4 blocks per wave per step
-    constexpr int STAGE_BYTES = (BM + BN) * 32 * 2;      // 32 KiB
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_n = (p.N + BN - 1) / BN;
-    int tm, tn;
-    tile_coords(xcd_remap(blockIdx.x, gridDim.x), gridDim.x / tiles_n, tiles_n, 4, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int fr = lane & 15, fg = lane >> 4;
-    if (m0 >= p.M) return;
-
-    const bf16_t* src[PW];
-#pragma unroll
-    for (int i = 0; i < PW; i++) {
-        const int blk = wave * PW + i;
-        if (blk < NA) {
-            int am = m0 + blk * 16 + fr;
-            if (am > p.M - 1) am = p.M - 1;
-            src[i] = (const bf16_t*)p.A + (((int64_t)(am >> 4) * (p.K >> 5) * 64) + (am & 15) + 16 * fg) * 8;
-        } else {
-            src[i] = (const bf16_t*)p.W + ((int64_t)((n0 >> 4) + blk - NA) * (p.K >> 5) * 64 + lane) * 8;
-        }
-    }
-    auto stage = [&](int buf, int ks) {
-        char* base = smem + buf * STAGE_BYTES + wave * (PW * 1024);
-#pragma unroll
-        for (int i = 0; i < PW; i++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)ks * 512),
-                                             (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
-    };
-    const int a_off = wm * TM * 1024 + lane * 16;
-    const int w_off = NA * 1024 + wn * TN * 1024 + lane * 16;
-    auto read_frags = [&](bf16x8 (&af)[TM], bf16x8 (&wf)[TN], int buf) {
-        const char* sbuf = smem + buf * STAGE_BYTES;
-#pragma unroll
-        for (int j = 0; j < TN; j++) wf[j] = *(const bf16x8*)(sbuf + w_off + j * 1024);
-#pragma unroll
-        for (int i = 0; i < TM; i++) af[i] = *(const bf16x8*)(sbuf + a_off + i * 1024);
-    };
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto mfma_all = [&](bf16x8 (&af)[TM], bf16x8 (&wf)[TN]) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    const int nt = p.K >> 5;            // k-steps; K % 64 == 0 -> nt even, nt >= 2
-    stage(0, 0);
-    stage(1, 1);
-    if (nt > 2) stage(2, 2);
-    if (nt > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();       // steps 0 and 1 are in LDS for every wave
-    bf16x8 afA[TM], wfA[TN], afB[TM], wfB[TN];
-    read_frags(afA, wfA, 0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // drain here so the loop body carries no pending LDS reads at its head
-    // one half-iteration: on entry set X holds step t (already read), steps t+1 (landed) and t+2 (maybe in flight)
-    auto half = [&](bf16x8 (&afX)[TM], bf16x8 (&wfX)[TN], bf16x8 (&afY)[TM], bf16x8 (&wfY)[TN], int t) {
-        if (t + 3 < nt) stage((t + 3) & 3, t + 3);
-        if (t + 1 < nt) read_frags(afY, wfY, (t + 1) & 3);
-        mfma_all(afX, wfX);
-        // the fragment reads of step t+1 (issued above, ~500 MFMA cycles ago) are retired here, where the
-        // wait is free; telling the compiler so keeps it from putting lgkmcnt(0) in FRONT of the next MFMAs
-        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
-        // step t+2 must have landed before the next half reads it; step t+3 may stay in flight
-        if (t + 3 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-    for (int t = 0; t < nt; t += 2) {
-        half(afA, wfA, afB, wfB, t);
-        half(afB, wfB, afA, wfA, t + 1);
-    }
-
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-        const int m = m0 + wm * (TM * 16) + i * 16 + fr;
-        if (EPI == EPI_QKV) {
-            const int head = (n0 + wn * 64) >> 6;
-            if (head * 64 < p.N) epilogue_qkv_head<4>(p, m, head, fg, acc[i]);
-        } else if (EPI == EPI_SWIGLU) {
-#pragma unroll
-            for (int j = 0; j < TN; j += 2) {
-                const int ntile = (n0 + wn * (TN * 16) + j * 16) >> 4;
-                epilogue_swiglu4<OutT>(p, m, (ntile >> 1) * 16 + 4 * fg, acc[i][j], acc[i][j + 1]);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-                epilogue4<EPI, OutT>(p, m, n0 + wn * (TN * 16) + j * 16 + 4 * fg, acc[i][j]);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // bf16 MFMA kernel, ping-pong form (prefill, tuning option 5): 256x256 tile, 8 waves as two groups of four (one wave
 // of each group per SIMD), K in 32-wide stages through a STAGES-slot LDS ring (4 slots = 128 KiB by default).  A stage is one PHASE for a wave:
 //   L: 12 fragment ds_reads of stage s, LDS-DMA issue of stage s+STAGES-1, lgkmcnt(0), counted vmcnt (stage s+1 landed)
@@ -945,7 +829,7 @@ static int g_narrow_waves = 1024;   // waves per narrow-form launch (nvl_set_tun
                                     // longer per-wave streams win: B=8 +8 %, B=16 +8 %, B=32 +3 % decode vs 4096
 static int g_wide_ksplit = 0;   // experiment (nvl_set_tuning key 4): K split of the wide form when groups <= 512
 static int g_force_ntw = 0, g_force_ksplit = 0;   // tuning overrides (nvl_bench_gemm only)
-static int g_force_tile = 0;                      // 0 automatic, 1: 128x128x2st, 2: 256x128x3st, 3: 256x256x2st
+static int g_force_tile = 0;                      // 0 automatic, 1: 128x128x2st, 2: 256x128x3st, 3: 256x256x2st, 5: ping-pong 256x256
 
 // skinny dispatch: M <= 64, no gather/segments.  Returns false when the shape is not eligible.
 template <int NTW, int EPI, typename OutT>
@@ -1074,17 +958,6 @@ static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
             else if (t2 >= 256 && cu_fill(t2, 1) >= 0.74) tile = 2;
         }
     }
-    if (tile == 4 && !a.seg && !a.a_rows) {
-        static bool attr4 = false;
-        if (!attr4) {
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_pipe_kernel<EPI, OutT>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            attr4 = true;
-        }
-        hipLaunchKernelGGL((gemm_bf16_pipe_kernel<EPI, OutT>), dim3(cdiv(a.M, 256) * cdiv(a.N, 256)), dim3(512),
-                           128 * 1024, st, a);
-        return;
-    }
 #define NVL_PP(TILE, ST, PR)                                                                                          \
     if (tile == TILE && !a.seg && !a.a_rows) {                                                                         \
         static bool attr = false;                                                                                      \
@@ -1098,8 +971,6 @@ static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
         return;                                                                                                        \
     }
     NVL_PP(5, 4, 0)      // the default large-M form: 4-slot ring (5 slots: -3 %, 3 slots: -3 %, r01 sweep)
-    NVL_PP(6, 4, 1)      // sweep: static priority for the late group instead of per-phase flips
-    NVL_PP(7, 4, 2)      // sweep: no priority changes
 #undef NVL_PP
     if (tile == 3) launch_gemm_tile<256, 256, 2, 4, 2, EPI, OutT>(st, a);
     else if (tile == 2) launch_gemm_tile<256, 128, 4, 2, 3, EPI, OutT>(st, a);

@@ -32,10 +32,10 @@ def test_matmul(gpu, oracle, m, k, n, precision):
     assert rel_err(got, want) <= (F32_TOL if precision == "f32" else BF16_TOL)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 5])
 @pytest.mark.parametrize("m,k,n", [(300, 128, 200), (517, 256, 384), (256, 64, 128)])
 def test_matmul_prefill_tile_kernels(gpu, oracle, tile, m, k, n):
-    """All prefill tile instances (128x128x2st, 256x128x3st, 256x256x2st) on ragged M/N edges."""
+    """All prefill tile instances (128x128x2st, 256x128x3st, 256x256x2st, 256x256 ping-pong) on ragged M/N edges."""
     r = rng(m + n)
     a = r.standard_normal((m, k), dtype=np.float32)
     b = r.standard_normal((k, n), dtype=np.float32) * 0.05
