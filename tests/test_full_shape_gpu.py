@@ -78,3 +78,40 @@ def test_device_path_properties_at_full_width(gpu, name):
     ref, _ = hm.forward_batch([6], [a + [nxt]], [0])
     assert rel_err(dec[0], ref[0]) <= TOL
     hm.close()
+
+
+def test_bench_sized_prefill_pingpong(gpu):
+    """The prefill form only BASELINE-sized batches reach (>= 256 tiles of 256x256: the ping-pong GEMM with its fused
+    QKV / SwiGLU / residual epilogues) at 16 x 512 tokens of Llama-3.2-1B-wide layers.  The oracle cannot run 8192
+    full-width tokens in test time, so: (a) the same batch in fp32 parity mode (validated against the oracle on the
+    small cases) within the bf16 tolerance, (b) a sequence's logits equal to its solo (small-M kernels) run."""
+    cfg = dict(gpu.synth.FULL_CONFIGS["llama-3.2-1b"], num_layers=2, vocab_size=4096)
+    w = gpu.synth.make_weights(cfg, seed=23, scale=0.02)
+    r = np.random.default_rng(8)
+    B, S = 16, 512
+    prompts = [r.integers(0, cfg["vocab_size"], S).tolist() for _ in range(B)]
+    hm = gpu.HipTransformerModel(cfg, w, precision="bf16", max_seqs=B, max_batch_tokens=B * S)
+    for i in range(B):
+        hm.seq_reset(i)
+    big, am_big = hm.forward_batch(list(range(B)), prompts, [0] * B)
+    assert hm.stats()["prefill_tokens"] == B * S
+    # (b) solo run of one sequence: lock-step tile kernels
+    hm.seq_reset(0)
+    solo, _ = hm.forward_batch([0], [prompts[3]], [0])
+    assert rel_err(big[3], solo[0]) <= 1e-2          # GEMM forms are bit-identical; the two norm kernels reduce in
+                                                     # different orders, which flips some bf16 roundings
+    # decode on top of the big prefill's cache (keys written by the fused QKV epilogue with the deferred scale)
+    for i in range(B):
+        hm.seq_reset(i)
+    hm.forward_batch(list(range(B)), prompts, [0] * B, want_logits=False)
+    dec, _ = hm.forward_batch(list(range(B)), [[int(t)] for t in am_big], [S] * B)
+    hm.close()
+    # (a) fp32 parity mode on the same batch
+    hf = gpu.HipTransformerModel(cfg, w, precision="f32", max_seqs=B, max_batch_tokens=B * S)
+    for i in range(B):
+        hf.seq_reset(i)
+    ref, _ = hf.forward_batch(list(range(B)), prompts, [0] * B)
+    assert rel_err(big, ref) <= TOL
+    dref, _ = hf.forward_batch(list(range(B)), [[int(t)] for t in am_big], [S] * B)
+    assert rel_err(dec, dref) <= TOL
+    hf.close()
