@@ -109,6 +109,10 @@ struct PendingResid {
     int slices;
     int rows_total;
     float alpha;
+    // MoE combine folded in (moe.go:105-120): when slot_of != NULL the "slices" of row r are the top_k expert outputs
+    // part[slot_of[r*slices + k]][H], weighted by gate_w[r*slices + k] — replaces moe_combine_kernel for decode
+    const int32_t* slot_of;
+    const float* gate_w;
 };
 // the arithmetic of one row once it sits in registers (shared by norm_row_kernel and decode_seam_kernel)
 template <typename ActT>
@@ -177,7 +181,14 @@ __global__ __launch_bounds__(256) void norm_row_kernel(float* __restrict__ x,
         v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (j < H4) {
             v[c] = *(const f32x4*)(xr + j * 4);
-            if (pr.part) {
+            if (pr.part && pr.slot_of) {
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < pr.slices; k++)          // same order and arithmetic as moe_combine_kernel
+                    s += pr.gate_w[(int64_t)src * pr.slices + k] *
+                         *(const f32x4*)(pr.part + (int64_t)pr.slot_of[(int64_t)src * pr.slices + k] * H + j * 4);
+                v[c] = v[c] + (pr.alpha != 0.f ? pr.alpha * s : s);
+                *(f32x4*)(xr + j * 4) = v[c];
+            } else if (pr.part) {
                 f32x4 s = *(const f32x4*)(pr.part + (int64_t)src * H + j * 4);
                 for (int k = 1; k < pr.slices; k++)
                     s += *(const f32x4*)(pr.part + ((int64_t)k * pr.rows_total + src) * H + j * 4);
@@ -405,14 +416,11 @@ __global__ __launch_bounds__(256) void decode_seam_kernel(const float* __restric
 // index first — the reference's sort.Slice is unstable, this is the documented tie rule),
 // weights renormalised over the chosen k.  One wave per token, E <= 64.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void moe_route_kernel(const float* __restrict__ router_logits, int ld,
-                                                        int rows, int E, int top_k,
-                                                        int32_t* __restrict__ expert_ids,   // [rows][k]
-                                                        float* __restrict__ expert_w) {     // [rows][k]
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    const float v = (lane < E) ? router_logits[(int64_t)r * ld + lane] : -INFINITY;
+// routing of one token by one wave (moe.go:63-103): softmax over E <= 64 experts, top-k by descending probability
+// (ties: lower expert index), weights renormalised over the chosen k
+__device__ __forceinline__ void moe_route_row(const float* __restrict__ logits_row, int E, int top_k, int lane,
+                                              int32_t* __restrict__ ids_row, float* __restrict__ w_row) {
+    const float v = (lane < E) ? logits_row[lane] : -INFINITY;
     const float mx = wave_max(v);
     const float e = (lane < E) ? expf(v - mx) : 0.f;
     const float s = wave_sum(e);
@@ -434,8 +442,77 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const float* __restrict_
         if (lane == bi) prob = -1.f;      // remove the winner
     }
     if (lane < top_k) {
-        expert_ids[(int64_t)r * top_k + lane] = my_e;
-        expert_w[(int64_t)r * top_k + lane] = my_w / wsum;   // moe.go:103
+        ids_row[lane] = my_e;
+        w_row[lane] = my_w / wsum;        // moe.go:103
+    }
+}
+__global__ __launch_bounds__(256) void moe_route_kernel(const float* __restrict__ router_logits, int ld,
+                                                        int rows, int E, int top_k,
+                                                        int32_t* __restrict__ expert_ids,   // [rows][k]
+                                                        float* __restrict__ expert_w) {     // [rows][k]
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    moe_route_row(router_logits + (int64_t)r * ld, E, top_k, lane, expert_ids + (int64_t)r * top_k, expert_w + (int64_t)r * top_k);
+}
+
+// Small batches (decode: rows * top_k <= MOE_PLAN_MAX_PAIRS): routing, the per-expert histogram, the segment scan with
+// the grouped GEMM's tile map, and the scatter of (token, expert) pairs into expert order — moe_route / hist / scan /
+// scatter above and the memset of the counters — as ONE single-workgroup launch.
+constexpr int MOE_PLAN_MAX_PAIRS = 2048, MOE_PLAN_MAX_E = 64;
+__global__ __launch_bounds__(256) void moe_plan_kernel(const float* __restrict__ router_logits, int ld, int rows, int E,
+                                                       int top_k, int BM, int32_t* __restrict__ expert_ids,
+                                                       float* __restrict__ expert_w, int32_t* __restrict__ seg_start,
+                                                       int32_t* __restrict__ tile_map, int32_t* __restrict__ n_mtiles,
+                                                       int32_t* __restrict__ perm_token, int32_t* __restrict__ slot_of) {
+    __shared__ int32_t ids[MOE_PLAN_MAX_PAIRS];
+    __shared__ int counts[MOE_PLAN_MAX_E], cursor[MOE_PLAN_MAX_E];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pairs = rows * top_k;
+    if (threadIdx.x < MOE_PLAN_MAX_E) counts[threadIdx.x] = 0;
+    for (int r = wave; r < rows; r += 4) {
+        moe_route_row(router_logits + (int64_t)r * ld, E, top_k, lane, expert_ids + (int64_t)r * top_k, expert_w + (int64_t)r * top_k);
+        // (re-derive my_e for the LDS copy: the lanes < top_k just wrote it)
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < pairs; i += 256) {
+        const int e = expert_ids[i];          // written by this workgroup above (visible after the barrier)
+        ids[i] = e;
+        atomicAdd(&counts[e], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int row = 0, nt = 0;
+        for (int e = 0; e < E; e++) {
+            const int c = counts[e];
+            seg_start[e] = row;
+            cursor[e] = row;
+            for (int r = 0; r < c; r += BM) {
+                tile_map[4 * nt] = e; tile_map[4 * nt + 1] = row + r; tile_map[4 * nt + 2] = (c - r < BM) ? (c - r) : BM;
+                tile_map[4 * nt + 3] = 0;
+                nt++;
+            }
+            row += c;
+        }
+        seg_start[E] = row;
+        *n_mtiles = nt;
+    }
+    __syncthreads();
+    // pairs of one expert keep their (token, rank) order: positions are handed out by a per-expert scan, not by atomics,
+    // so the row order inside a segment — and with it every output bit — is the same on every run
+    for (int e = wave; e < E; e += 4) {
+        int base = cursor[e];
+        for (int i0 = 0; i0 < pairs; i0 += 64) {
+            const int i = i0 + lane;
+            const bool mine = i < pairs && ids[i] == e;
+            const unsigned long long b = __ballot(mine);
+            if (mine) {
+                const int pos = base + __popcll(b & ((1ull << lane) - 1ull));
+                perm_token[pos] = i / top_k;
+                slot_of[i] = pos;
+            }
+            base += __popcll(b);
+        }
     }
 }
 

@@ -109,6 +109,7 @@ struct nvl_model {
     // decode split-K: partial slices of the last residual GEMM, consumed by the next norm launch
     float* rs_part = nullptr;    // deferred RMSNorm: [H/16][64] partial sums of x^2 (gemm.h)
     float* sk_part = nullptr; int sk_max_slices = 4; int pending_slices = 0, pending_rows = 0; float pending_alpha = 1.f; const float* pending_part = nullptr;
+    const int32_t* pending_slot_of = nullptr; const float* pending_gate_w = nullptr;   // MoE combine folded into the next norm
     // per-call metadata (one pinned host block mirrored on the device)
     int32_t* meta_host = nullptr; int32_t* meta_dev = nullptr; int64_t meta_ints = 0;
     SampleBufs samp;             // nvl_sample scratch

@@ -771,10 +771,11 @@ template <typename ActT>
 void launch_norm(nvl_model* m, float* x, const int32_t* rows_idx, const float* w, const float* b,
                  void* y, int rows) {
     KScope ks(m, KC_OTHER);
-    PendingResid pr{nullptr, 0, 0, 0.f};
+    PendingResid pr{nullptr, 0, 0, 0.f, nullptr, nullptr};
     if (m->pending_slices > 0) {            // complete the residual add the previous decode GEMM left as split-K slices
         pr.part = m->pending_part; pr.slices = m->pending_slices; pr.rows_total = m->pending_rows; pr.alpha = m->pending_alpha;
-        m->pending_slices = 0;
+        pr.slot_of = m->pending_slot_of; pr.gate_w = m->pending_gate_w;
+        m->pending_slices = 0; m->pending_slot_of = nullptr; m->pending_gate_w = nullptr;
         if (!(rows <= 512 && m->H <= 1024 * NORM_ROW_MAXCH)) throw std::runtime_error("norm: pending residual needs the row kernel");
     }
     if (rows <= 512 && m->H <= 1024 * NORM_ROW_MAXCH)
@@ -894,6 +895,7 @@ void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
 // Prefill and the fp32 mode fuse the add into the GEMM epilogue.  Decode-sized batches split K over
 // `slices` workgroups per column block so that all 256 CUs stream weights (a 2048-column projection has
 // only 128 column blocks), and leave the add to the norm kernel that always follows (PendingResid).
+static int g_moe_small = 1;    // nvl_set_tuning key 8: fused MoE planning launch + combine folded into the next norm (0 = off)
 static int g_decode_seam = 1;  // nvl_set_tuning key 7: decode_seam_kernel in nvl_decode_greedy (0 = separate kernels)
 static int g_defer_norm = 1;   // nvl_set_tuning key 3: deferred RMSNorm between O-proj and FFN-up in decode (0 = off)
 static int g_sk_slices = 0;    // tuning override (nvl_set_tuning key 1): 0 automatic, 1 = never split
@@ -971,7 +973,14 @@ void moe(nvl_model* m, const LayerW& l, int M) {
     const int E = c.num_experts, k = c.num_experts_per_tok, I = m->F, H = m->H;
     const int pairs = M * k;
     gemm(m, EPI_STORE, true, mk(m->xn, H, l.t[NVL_T_ROUTER].p, m->router_logits, 128, nullptr, 1.f, M, E, H));
-    {
+    // decode-sized batches: one planning launch, and the weighted combine rides on the norm that follows
+    const bool small = !m->f32 && M <= 64 && pairs <= MOE_PLAN_MAX_PAIRS && E <= MOE_PLAN_MAX_E && g_moe_small;
+    if (small) {
+        KScope ks(m, KC_OTHER);
+        hipLaunchKernelGGL(moe_plan_kernel, dim3(1), dim3(256), 0, m->stream, m->router_logits, 128, M, E, k, 128, m->expert_ids,
+                           m->expert_w, m->seg_start, m->moe_tile_map, m->moe_n_mtiles, m->perm_token, m->slot_of);
+        NVL_HIP(hipGetLastError());
+    } else {
         KScope ks(m, KC_OTHER);
         NVL_HIP(hipMemsetAsync(m->moe_counts, 0, (size_t)E * 4, m->stream));
         hipLaunchKernelGGL(moe_route_kernel, dim3(cdiv(M, 4)), dim3(256), 0, m->stream, m->router_logits, 128, M, E, k,
@@ -1013,7 +1022,11 @@ void moe(nvl_model* m, const LayerW& l, int M) {
         d.tile_map = m->moe_tile_map; d.n_mtiles = m->moe_n_mtiles; d.w_expert_stride = (int64_t)H * I;
         gemm(m, EPI_STORE, true, d, 2.0 * pairs * H * I);
     }
-    {
+    if (small && !m->keep_hidden && m->pending_slices == 0 && H % 4 == 0 && H <= 1024 * NORM_ROW_MAXCH) {
+        // x += rm * sum_k w[t][k] * eo[slot[t][k]] is completed by the next norm's read of x (PendingResid)
+        m->pending_part = m->moe_eo; m->pending_slices = k; m->pending_rows = M; m->pending_alpha = c.residual_multiplier;
+        m->pending_slot_of = m->slot_of; m->pending_gate_w = m->expert_w;
+    } else {
         KScope ks(m, KC_OTHER);
         hipLaunchKernelGGL(moe_combine_kernel, dim3(M), dim3(256), 0, m->stream, m->moe_eo, m->slot_of, m->expert_w, k,
                            c.residual_multiplier, m->x, H, 1);

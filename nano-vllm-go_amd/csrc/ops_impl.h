@@ -297,6 +297,7 @@ extern "C" int nvl_op_moe(int device, int precision, const float* x, const float
     if (m.f32) m.h2 = (float*)cx.alloc(pairs * 2 * inter * 4);
     m.x = (float*)cx.alloc((int64_t)rows * hidden * 4);
     NVL_HIP(hipMemsetAsync(m.x, 0, (size_t)rows * hidden * 4, m.stream));
+    m.keep_hidden = true;   // (no norm follows here: keep the stand-alone combine instead of leaving it pending)
     moe(&m, l, rows);    // accumulates into x (zeroed) with multiplier 1
     cx.down(y, m.x, (int64_t)rows * hidden);
     l.moe_in = nullptr; l.t[NVL_T_ROUTER].p = nullptr; l.t[NVL_T_MOE_OUT].p = nullptr;
@@ -394,6 +395,7 @@ extern "C" int nvl_bench_gemm(int device, int M, int N, int K, int epi, int forc
 extern "C" int nvl_set_tuning(int key, int value) {
     if (key == 0) { const int old = g_force_tile; g_force_tile = value; return old; }
     if (key == 1) { const int old = g_sk_slices; g_sk_slices = value; return old; }
+    if (key == 8) { const int old = g_moe_small; g_moe_small = value; return old; }
     if (key == 7) { const int old = g_decode_seam; g_decode_seam = value; return old; }
     if (key == 6) { const int old = g_msplit_ks; g_msplit_ks = value; return old; }
     if (key == 5) { const int old = g_narrow_waves; g_narrow_waves = value; return old; }
