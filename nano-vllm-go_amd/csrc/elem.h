@@ -466,36 +466,42 @@ __global__ __launch_bounds__(256) void moe_plan_kernel(const float* __restrict__
                                                        int32_t* __restrict__ tile_map, int32_t* __restrict__ n_mtiles,
                                                        int32_t* __restrict__ perm_token, int32_t* __restrict__ slot_of) {
     __shared__ int32_t ids[MOE_PLAN_MAX_PAIRS];
+    __shared__ float gw[MOE_PLAN_MAX_PAIRS];
     __shared__ int counts[MOE_PLAN_MAX_E], cursor[MOE_PLAN_MAX_E];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pairs = rows * top_k;
     if (threadIdx.x < MOE_PLAN_MAX_E) counts[threadIdx.x] = 0;
-    for (int r = wave; r < rows; r += 4) {
-        moe_route_row(router_logits + (int64_t)r * ld, E, top_k, lane, expert_ids + (int64_t)r * top_k, expert_w + (int64_t)r * top_k);
-        // (re-derive my_e for the LDS copy: the lanes < top_k just wrote it)
-    }
+    for (int r = wave; r < rows; r += 4)          // one wave per token; results stay in LDS for the phases below
+        moe_route_row(router_logits + (int64_t)r * ld, E, top_k, lane, ids + r * top_k, gw + r * top_k);
     __syncthreads();
     for (int i = threadIdx.x; i < pairs; i += 256) {
-        const int e = expert_ids[i];          // written by this workgroup above (visible after the barrier)
-        ids[i] = e;
+        const int e = ids[i];
+        expert_ids[i] = e;
+        expert_w[i] = gw[i];
         atomicAdd(&counts[e], 1);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int row = 0, nt = 0;
-        for (int e = 0; e < E; e++) {
-            const int c = counts[e];
-            seg_start[e] = row;
-            cursor[e] = row;
-            for (int r = 0; r < c; r += BM) {
-                tile_map[4 * nt] = e; tile_map[4 * nt + 1] = row + r; tile_map[4 * nt + 2] = (c - r < BM) ? (c - r) : BM;
-                tile_map[4 * nt + 3] = 0;
-                nt++;
-            }
-            row += c;
+    if (wave == 0) {
+        // exclusive scans over the experts (E <= 64: one lane each): first row and first m-tile of every segment
+        const int c = lane < E ? counts[lane] : 0;
+        const int nt_e = (c + BM - 1) / BM;
+        int row = c, tile = nt_e;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int yr = __shfl_up(row, o, 64), yt = __shfl_up(tile, o, 64);
+            if (lane >= o) { row += yr; tile += yt; }
         }
-        seg_start[E] = row;
-        *n_mtiles = nt;
+        const int row0 = row - c, tile0 = tile - nt_e;
+        if (lane < E) {
+            seg_start[lane] = row0;
+            cursor[lane] = row0;
+            for (int t = 0; t < nt_e; t++) {
+                const int r = t * BM;
+                tile_map[4 * (tile0 + t)] = lane; tile_map[4 * (tile0 + t) + 1] = row0 + r;
+                tile_map[4 * (tile0 + t) + 2] = (c - r < BM) ? (c - r) : BM; tile_map[4 * (tile0 + t) + 3] = 0;
+            }
+        }
+        if (lane == 63) { seg_start[E] = row; *n_mtiles = tile; }
     }
     __syncthreads();
     // pairs of one expert keep their (token, rank) order: positions are handed out by a per-expert scan, not by atomics,
