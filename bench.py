@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--cpu-gen", type=int, default=4)
     ap.add_argument("--tp", action="store_true", help="all ranks form ONE tensor-parallel group (RCCL all-reduce) "
                     "and process the same batch: strong scaling, e.g. --model llama-3-8b --gpus 8 --tp")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="control-flow rehearsal of the multi-rank path on a box with ONE GPU: every rank uses device 0 and "
+                         "the rendezvous/barrier/max-reduce run over gloo (the printed value is meaningless)")
     ap.add_argument("--tune", default="", help="nvl_set_tuning overrides, e.g. 1=2 (key=value, comma separated)")
     return ap.parse_args()
 
@@ -150,12 +153,17 @@ def main():
     import torch.distributed as dist
 
     pkg = importlib.import_module("nano-vllm-go_amd")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     assert pkg.lib().nvl_device_count() > local_rank, "bench.py needs a GPU: the HIP path has no CPU fallback"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
@@ -227,7 +235,8 @@ def main():
         dec_s += d
     sync_all()
     elapsed = time.perf_counter() - t_start
-    times = torch.tensor([elapsed, pre_s, dec_s], dtype=torch.float64, device=device)
+    times = torch.tensor([elapsed, pre_s, dec_s], dtype=torch.float64,
+                         device="cpu" if args.rehearse_on_one_gpu else device)
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     elapsed, pre_s, dec_s = [float(x) for x in times.cpu()]
