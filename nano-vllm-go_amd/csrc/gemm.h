@@ -402,9 +402,10 @@ void gemm_bf16_kernel(GemmArgs p) {
 // after its last readers retired their ds_reads before the barrier that ended L(s-1) of the LATE group (WAR);
 // stage s+1 is waited for at the end of L(s) by every wave, one barrier before the early group reads it (RAW).
 // ------------------------------------------------------------------------------------------
-template <int EPI, typename OutT, int STAGES = 4, int PRIO = 0>
+template <int EPI, typename OutT, int STAGES = 4, int PRIO = 0, int WAVES_N = 4>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmArgs p) {
-    constexpr int BM = 256, BN = 256, WAVES_N = 4, TM = 8, TN = 4;
+    // WAVES_N = 4: wave tile 128x64 (a head of 64 per wave); WAVES_N = 2: wave tile 64x128 (a head of 128 per wave)
+    constexpr int BM = 256, BN = 256, WAVES_M = 8 / WAVES_N, TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
     constexpr int NA = BM / 16, NB = BN / 16;            // 1-KiB blocks per stage (one k-step)
     constexpr int PW = (NA + NB) / 8;                    // 4 blocks per wave per stage
     constexpr int STAGE_BYTES = (BM + BN) * 32 * 2;      // 32 KiB
@@ -415,7 +416,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmArgs p) {
     int tm, tn;
     tile_coords(xcd_remap(blockIdx.x, gridDim.x), gridDim.x / tiles_n, tiles_n, 4, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;   // wm = the ping-pong group
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int grp = wave >> 2;                            // the ping-pong group: first / second dispatched half
     const int fr = lane & 15, fg = lane >> 4;
     if (m0 >= p.M) return;
 
@@ -461,8 +463,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmArgs p) {
     static_assert(STAGES >= 3 && STAGES <= 5, "vmcnt immediates above cover up to three stages in flight");
     wait_younger((nt < STAGES - 1 ? nt : STAGES - 1) - 1);
     __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();          // the late group: one phase behind from here on
-    if (PRIO == 1 && wm == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the second-dispatched half
+    if (grp == 1) __builtin_amdgcn_s_barrier();         // the late group: one phase behind from here on
+    if (PRIO == 1 && grp == 1) __builtin_amdgcn_s_setprio(1);  // static priority for the second-dispatched half
     int buf = 0;
     for (int s = 0; s < nt; s++) {
         // ---- L phase ----
@@ -496,14 +498,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
-    if (wm == 0) __builtin_amdgcn_s_barrier();          // pairs with the late group's last barrier
+    if (grp == 0) __builtin_amdgcn_s_barrier();         // pairs with the late group's last barrier
 
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int m = m0 + wm * (TM * 16) + i * 16 + fr;
         if (EPI == EPI_QKV) {
-            const int head = (n0 + wn * 64) >> 6;
-            if (head * 64 < p.N) epilogue_qkv_head<4>(p, m, head, fg, acc[i]);
+            const int head = (n0 + wn * (TN * 16)) / (TN * 16);      // the wave's column block is exactly one head
+            if (head * (TN * 16) < p.N) epilogue_qkv_head<TN>(p, m, head, fg, acc[i]);
         } else if (EPI == EPI_SWIGLU) {
 #pragma unroll
             for (int j = 0; j < TN; j += 2) {
@@ -945,6 +947,17 @@ static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
     if (launch_gemm_skinny_bf16<EPI, OutT>(st, a)) return;
     if constexpr (EPI == EPI_QKV) {
         if (a.qkv.hd == 128) {     // a wave must own a whole 128-column head: 256x256 tile as 4x2 waves of 64x128
+            const int t3 = cdiv(a.M, 256) * cdiv(a.N, 256);
+            if (g_force_tile == 0 && t3 >= 256 && cu_fill(t3, 1) >= 0.74 && a.K >= 160 && !a.seg && !a.a_rows) {
+                static bool attr = false;     // the ping-pong form, wave tile 64x128
+                if (!attr) {
+                    (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI, OutT, 4, 0, 2>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 1024);
+                    attr = true;
+                }
+                hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, OutT, 4, 0, 2>), dim3(t3), dim3(512), 4 * 32 * 1024, st, a);
+                return;
+            }
             launch_gemm_tile<256, 256, 4, 2, 2, EPI, OutT>(st, a);
             return;
         }

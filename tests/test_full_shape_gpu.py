@@ -80,15 +80,16 @@ def test_device_path_properties_at_full_width(gpu, name):
     hm.close()
 
 
-def test_bench_sized_prefill_pingpong(gpu):
+@pytest.mark.parametrize("key,layers,B", [("llama-3.2-1b", 2, 16), ("llama-3-8b", 1, 8)])   # hd 64 / hd 128 QKV epilogues
+def test_bench_sized_prefill_pingpong(gpu, key, layers, B):
     """The prefill form only BASELINE-sized batches reach (>= 256 tiles of 256x256: the ping-pong GEMM with its fused
     QKV / SwiGLU / residual epilogues) at 16 x 512 tokens of Llama-3.2-1B-wide layers.  The oracle cannot run 8192
     full-width tokens in test time, so: (a) the same batch in fp32 parity mode (validated against the oracle on the
     small cases) within the bf16 tolerance, (b) a sequence's logits equal to its solo (small-M kernels) run."""
-    cfg = dict(gpu.synth.FULL_CONFIGS["llama-3.2-1b"], num_layers=2, vocab_size=4096)
+    cfg = dict(gpu.synth.FULL_CONFIGS[key], num_layers=layers, vocab_size=4096)
     w = gpu.synth.make_weights(cfg, seed=23, scale=0.02)
     r = np.random.default_rng(8)
-    B, S = 16, 512
+    S = 512
     prompts = [r.integers(0, cfg["vocab_size"], S).tolist() for _ in range(B)]
     hm = gpu.HipTransformerModel(cfg, w, precision="bf16", max_seqs=B, max_batch_tokens=B * S)
     for i in range(B):
