@@ -213,6 +213,10 @@ int nvl_forward_paged(nvl_model* m, int n_seqs, const int32_t* tokens, const int
 int nvl_runner_run_paged(nvl_model* m, int n_seqs, const int32_t* const* token_ptrs, const int32_t* token_lens,
                          const int32_t* num_cached_tokens, const int32_t* const* block_table_ptrs,
                          const int32_t* block_table_lens, int is_prefill, int32_t* next_tokens, float* logits_out);
+/* nvl_decode_greedy for a paged-KV model.  positions[i] = tokens already cached for sequence i; its block table must
+ * cover positions[i] + n_steps tokens (the block manager allocates ahead).  out_tokens [n_steps][n_seqs]. */
+int nvl_decode_greedy_paged(nvl_model* m, int n_seqs, const int32_t* first_tokens, const int32_t* positions, int n_steps,
+                            const int32_t* block_tables, const int32_t* table_offsets, int32_t* out_tokens);
 /* Debug/parity for paged mode: the K and V rows of `n_tokens` positions of one block list, as nvl_get_kv. */
 int nvl_get_kv_paged(nvl_model* m, const int32_t* block_table, int n_blocks, int n_tokens, int layer, float* k_out,
                      float* v_out);

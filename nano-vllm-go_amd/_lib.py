@@ -115,6 +115,7 @@ def lib():
     L.nvl_decode_greedy.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
     L.nvl_forward_paged.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]
     L.nvl_runner_run_paged.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp]
+    L.nvl_decode_greedy_paged.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp]
     L.nvl_get_kv_paged.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.nvl_set_debug.argtypes = [vp, C.c_int]
     L.nvl_get_hidden.argtypes = [vp, C.c_int, vp, i64]

@@ -1388,35 +1388,12 @@ extern "C" int nvl_runner_run_paged(nvl_model* m, int n_seqs, const int32_t* con
     return NVL_OK;
 }
 
-// The greedy decode loop of cmd/ask (main.go:315-360, without the EOS stop) as ONE call: `n_steps` forward passes of one
-// token per sequence, each step's argmax fed back on the device — no host round trip between steps.  Identical
-// arithmetic to calling nvl_forward n_steps times with the returned tokens.
-extern "C" int nvl_decode_greedy(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* first_tokens,
-                                 int n_steps, int32_t* out_tokens) {
-    if (!m) return NVL_ERR_INVALID;
-    if (!m->finalized) return fail(m, NVL_ERR_STATE, "nvl_decode_greedy: model not finalized");
-    if (n_seqs <= 0 || n_steps <= 0 || !seq_ids || !first_tokens || !out_tokens)
-        return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy: null/empty arguments");
-    if (n_seqs > m->opts.max_seqs || n_seqs > m->opts.max_batch_tokens)
-        return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy: n_seqs exceeds max_seqs / max_batch_tokens");
-    NVL_TRY(m)
-    NVL_HIP(hipSetDevice(m->device));
-    if (m->paged) return fail(m, NVL_ERR_STATE, "nvl_decode_greedy: not available in paged-KV mode");
+namespace {
+// the n_steps decode passes of nvl_decode_greedy[_paged]: metadata for step 0 is in meta_host (one token per sequence),
+// every later step's tokens / positions are produced on the device
+void decode_loop(nvl_model* m, const Meta& hm, int n_seqs, int n_steps, int32_t* out_tokens) {
     const int M = n_seqs;
-    const Meta hm = bind_meta(m, m->meta_host, M);
-    int32_t *h_sts = hm.seq_tok_start, *h_len = hm.seq_len, *h_pos = hm.seq_pos, *h_tbl = hm.seq_tbl, *h_last = hm.last_rows,
-            *h_tokens = hm.tokens, *h_tok_pos = hm.tok_pos, *h_tok_tbl = hm.tok_tbl;
-    std::vector<int> h_slot((size_t)n_seqs);
-    for (int i = 0; i < n_seqs; i++) {
-        auto it = m->seq_slot.find(seq_ids[i]);
-        if (it == m->seq_slot.end()) return fail(m, NVL_ERR_UNKNOWN_SEQ, "nvl_decode_greedy: sequence has no KV slot");
-        for (int j = 0; j < i; j++) if (seq_ids[j] == seq_ids[i]) return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy: duplicate sequence");
-        const int slot = it->second, pos = m->slot_len[(size_t)slot];
-        if (pos + n_steps > m->cfg.max_seq_len) return fail(m, NVL_ERR_POSITION, "nvl_decode_greedy: position exceeds max_seq_len");
-        if (first_tokens[i] < 0 || first_tokens[i] >= m->V) return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy: token id out of range");
-        h_sts[i] = i; h_len[i] = 1; h_pos[i] = pos; h_slot[(size_t)i] = slot; h_last[i] = i; h_tbl[i] = i; hm.blk_table[i] = slot;
-        h_tokens[i] = first_tokens[i]; h_tok_pos[i] = pos; h_tok_tbl[i] = i;
-    }
+    const int32_t* h_pos = hm.seq_pos;
     const Meta md = bind_meta(m, m->meta_dev, M);
     if ((int64_t)n_steps * n_seqs > m->ring_ints) {
         dfree(m->ring);
@@ -1453,12 +1430,83 @@ extern "C" int nvl_decode_greedy(nvl_model* m, int n_seqs, const int64_t* seq_id
     NVL_HIP(hipEventRecord(m->ev1, m->stream));
     NVL_HIP(hipMemcpyAsync(out_tokens, m->ring, (size_t)n_steps * n_seqs * 4, hipMemcpyDeviceToHost, m->stream));
     NVL_HIP(hipStreamSynchronize(m->stream));
-    for (int i = 0; i < n_seqs; i++) m->slot_len[(size_t)h_slot[(size_t)i]] += n_steps;
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, m->ev0, m->ev1);
     m->stats.forward_calls += (uint64_t)n_steps;
     m->stats.decode_tokens += (uint64_t)n_steps * n_seqs; m->stats.decode_ms += ms;
     if (m->profile) drain_profile(m);
+}
+}  // namespace
+
+// The greedy decode loop of cmd/ask (main.go:315-360, without the EOS stop) as ONE call: `n_steps` forward passes of one
+// token per sequence, each step's argmax fed back on the device — no host round trip between steps.  Identical
+// arithmetic to calling nvl_forward n_steps times with the returned tokens.
+extern "C" int nvl_decode_greedy(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* first_tokens,
+                                 int n_steps, int32_t* out_tokens) {
+    if (!m) return NVL_ERR_INVALID;
+    if (!m->finalized) return fail(m, NVL_ERR_STATE, "nvl_decode_greedy: model not finalized");
+    if (n_seqs <= 0 || n_steps <= 0 || !seq_ids || !first_tokens || !out_tokens)
+        return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy: null/empty arguments");
+    if (n_seqs > m->opts.max_seqs || n_seqs > m->opts.max_batch_tokens)
+        return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy: n_seqs exceeds max_seqs / max_batch_tokens");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    if (m->paged) return fail(m, NVL_ERR_STATE, "nvl_decode_greedy: not available in paged-KV mode");
+    const int M = n_seqs;
+    const Meta hm = bind_meta(m, m->meta_host, M);
+    int32_t *h_sts = hm.seq_tok_start, *h_len = hm.seq_len, *h_pos = hm.seq_pos, *h_tbl = hm.seq_tbl, *h_last = hm.last_rows,
+            *h_tokens = hm.tokens, *h_tok_pos = hm.tok_pos, *h_tok_tbl = hm.tok_tbl;
+    std::vector<int> h_slot((size_t)n_seqs);
+    for (int i = 0; i < n_seqs; i++) {
+        auto it = m->seq_slot.find(seq_ids[i]);
+        if (it == m->seq_slot.end()) return fail(m, NVL_ERR_UNKNOWN_SEQ, "nvl_decode_greedy: sequence has no KV slot");
+        for (int j = 0; j < i; j++) if (seq_ids[j] == seq_ids[i]) return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy: duplicate sequence");
+        const int slot = it->second, pos = m->slot_len[(size_t)slot];
+        if (pos + n_steps > m->cfg.max_seq_len) return fail(m, NVL_ERR_POSITION, "nvl_decode_greedy: position exceeds max_seq_len");
+        if (first_tokens[i] < 0 || first_tokens[i] >= m->V) return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy: token id out of range");
+        h_sts[i] = i; h_len[i] = 1; h_pos[i] = pos; h_slot[(size_t)i] = slot; h_last[i] = i; h_tbl[i] = i; hm.blk_table[i] = slot;
+        h_tokens[i] = first_tokens[i]; h_tok_pos[i] = pos; h_tok_tbl[i] = i;
+    }
+    decode_loop(m, hm, n_seqs, n_steps, out_tokens);
+    for (int i = 0; i < n_seqs; i++) m->slot_len[(size_t)h_slot[(size_t)i]] += n_steps;
+    return NVL_OK;
+    NVL_CATCH(m)
+}
+
+// nvl_decode_greedy for a paged-KV model: positions[i] tokens are cached (the sequence length before the first
+// generated token is appended); the block tables must already cover positions[i] + n_steps tokens (the host's block
+// manager allocates ahead: BlockManager.MayAppend per step, block_manager.go:231-263).
+extern "C" int nvl_decode_greedy_paged(nvl_model* m, int n_seqs, const int32_t* first_tokens, const int32_t* positions,
+                                       int n_steps, const int32_t* block_tables, const int32_t* table_offsets,
+                                       int32_t* out_tokens) {
+    if (!m) return NVL_ERR_INVALID;
+    if (!m->finalized) return fail(m, NVL_ERR_STATE, "nvl_decode_greedy_paged: model not finalized");
+    if (!m->paged) return fail(m, NVL_ERR_STATE, "nvl_decode_greedy_paged: the model was created without kv_num_blocks");
+    if (n_seqs <= 0 || n_steps <= 0 || !first_tokens || !positions || !block_tables || !table_offsets || !out_tokens)
+        return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy_paged: null/empty arguments");
+    if (n_seqs > m->opts.max_seqs || n_seqs > m->opts.max_batch_tokens)
+        return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy_paged: n_seqs exceeds max_seqs / max_batch_tokens");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    const int M = n_seqs, BS = m->Tmax;
+    const Meta hm = bind_meta(m, m->meta_host, M);
+    for (int i = 0; i < n_seqs; i++) {
+        const int pos = positions[i], end = pos + n_steps;
+        if (pos < 0) return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy_paged: negative position");
+        if (end > m->cfg.max_seq_len) return fail(m, NVL_ERR_POSITION, "nvl_decode_greedy_paged: position exceeds max_seq_len");
+        if (first_tokens[i] < 0 || first_tokens[i] >= m->V) return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy_paged: token id out of range");
+        const int nb = table_offsets[i + 1] - table_offsets[i];
+        if (nb < cdiv(end, BS) || nb > m->blocks_per_seq) return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy_paged: block table does not cover the generated positions");
+        const int tb = i * m->blocks_per_seq;
+        for (int j = 0; j < nb; j++) {
+            const int b = block_tables[table_offsets[i] + j];
+            if (b < 0 || b >= m->num_blocks) return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy_paged: block id out of range");
+            hm.blk_table[tb + j] = b;
+        }
+        hm.seq_tok_start[i] = i; hm.seq_len[i] = 1; hm.seq_pos[i] = pos; hm.seq_tbl[i] = tb; hm.last_rows[i] = i;
+        hm.tokens[i] = first_tokens[i]; hm.tok_pos[i] = pos; hm.tok_tbl[i] = tb;
+    }
+    decode_loop(m, hm, n_seqs, n_steps, out_tokens);
     return NVL_OK;
     NVL_CATCH(m)
 }

@@ -189,6 +189,18 @@ class HipTransformerModel:
                                            L.FWD_ALL_LOGITS if all_logits else 0, _ptr(logits), _ptr(am)), self.h)
         return logits, am
 
+    def decode_greedy_paged(self, first_tokens, positions, n_steps: int, block_tables):
+        """nvl_decode_greedy_paged -> [n_steps, n_seqs]; the tables must cover positions + n_steps tokens."""
+        n = len(first_tokens)
+        first = np.ascontiguousarray(first_tokens, dtype=np.int32)
+        pos = np.ascontiguousarray(positions, dtype=np.int32)
+        tbl = np.concatenate([np.asarray(b, np.int32) for b in block_tables]).astype(np.int32)
+        off = np.concatenate([[0], np.cumsum([len(b) for b in block_tables])]).astype(np.int32)
+        out = np.empty((n_steps, n), dtype=np.int32)
+        L.check(self.lib.nvl_decode_greedy_paged(self.h, n, _ptr(first), _ptr(pos), n_steps, _ptr(tbl), _ptr(off), _ptr(out)),
+                self.h)
+        return out
+
     def get_kv_paged(self, block_table, n_tokens: int, layer: int):
         tbl = np.ascontiguousarray(block_table, dtype=np.int32)
         nkv = self.cfg["num_heads"] if self.cfg["attention_type"] == "mha" else (

@@ -135,3 +135,40 @@ def test_paged_mode_argument_errors(gpu, oracle):
     with pytest.raises(gpu.NvlError):                      # past max_seq_len (rope.go:84-86 would panic)
         paged.forward_paged([toks], [cfg["max_seq_len"] - 1], [[0, 1, 2, 3]])
     slab.close(); paged.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_fused_greedy_loop_over_block_tables(gpu, oracle, precision):
+    """nvl_decode_greedy_paged: n steps with the token feedback on the device, KV appended through block tables that the
+    block manager extended ahead (MayAppend per step) — ids identical to the slab model's nvl_decode_greedy and to the
+    step-by-step paged loop; crosses block boundaries."""
+    cfg, om, slab, paged = models(gpu, oracle, "llama", precision)
+    r = np.random.default_rng(24)
+    bm = BlockManager(24, BS)
+    seqs = [gpu.Sequence(seq_id=i, token_ids=r.integers(0, cfg["vocab_size"], n).tolist(), block_size=BS)
+            for i, n in enumerate((60, 100, 7))]
+    steps = 40
+    for s in seqs:
+        bm.allocate(s)
+        slab.seq_reset(s.seq_id)
+    _, first = paged.forward_paged([s.token_ids for s in seqs], [0, 0, 0], [s.block_table for s in seqs], want_logits=False)
+    _, first_s = slab.forward_batch([0, 1, 2], [s.token_ids for s in seqs], [0, 0, 0], want_logits=False)
+    assert np.array_equal(first, first_s)
+    # allocate ahead: the scheduler would call MayAppend after each AppendToken; do it with placeholder tokens
+    ahead = []
+    for s in seqs:
+        t = gpu.Sequence(seq_id=s.seq_id, token_ids=list(s.token_ids), block_table=list(s.block_table), block_size=BS)
+        for _ in range(steps):
+            t.append_token(0)
+            if len(t.token_ids) % BS == 1:                 # only the new-block branch matters for the table
+                bid = bm.free[0]
+                bm._allocate_block(bid)
+                t.block_table.append(bid)
+        ahead.append(t.block_table)
+    pos = [len(s) for s in seqs]
+    got = paged.decode_greedy_paged(first, pos, steps, ahead)
+    want = slab.decode_greedy([0, 1, 2], first_s, steps)
+    assert np.array_equal(got, want)
+    with pytest.raises(gpu.NvlError):                      # tables that stop short of the generated positions
+        paged.decode_greedy_paged(first, pos, steps, [s.block_table for s in seqs])
+    slab.close(); paged.close()
