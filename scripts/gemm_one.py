@@ -1,7 +1,7 @@
 """Run ONE projection GEMM shape repeatedly (for rocprofv3 --pmc / --kernel-trace runs).
 usage: gemm_one.py M N K epi tile iters"""
 import ctypes as C, importlib, sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 p = importlib.import_module('nano-vllm-go_amd')
 M, N, K, epi, tile, iters = map(int, sys.argv[1:7])
 us = C.c_float()
