@@ -96,3 +96,27 @@ def test_from_pretrained_directory(gpu, oracle, tmp_path):
     prompt = [5, 17, 300, 42, 9]
     assert hm.greedy(prompt, 6) == om.greedy(prompt, 6)
     hm.close()
+
+
+def test_plain_c_consumer_of_the_abi(gpu, tmp_path):
+    """examples/ask_greedy.c — config.json + safetensors -> nvl_create / nvl_load_safetensors / nvl_forward /
+    nvl_decode_greedy from C alone (what the cgo shim does) — prints the same greedy ids as the Python mirror."""
+    import pathlib
+    import subprocess
+    root = pathlib.Path(__file__).resolve().parents[1]
+    exe = root / "examples" / "ask_greedy"
+    if not exe.exists():
+        pytest.skip("examples/ask_greedy not built (python -c 'import __graft_entry__ as g; g.build()')")
+    cfg = gpu.synth.tiny_config("llama", tied_embedding=False)
+    w = gpu.synth.make_weights(cfg, seed=15, scale=0.05, peaked_head=4.0)
+    path = write_checkpoint(tmp_path / "c_dir", cfg, w, "llama", shards=2)
+    prompt = [11, 5, 300, 42, 9, 77]
+    hm = gpu.HipTransformerModel.from_pretrained(str(path), precision="bf16", max_seqs=1, max_batch_tokens=64)
+    want = hm.greedy_fused(prompt, 9)
+    hm.close()
+    out = subprocess.run([str(exe), str(path), "9"] + [str(t) for t in prompt], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert [int(t) for t in out.stdout.split()] == want
+    assert "tok/s" in out.stderr
+    bad = subprocess.run([str(exe), str(tmp_path / "nope"), "3", "1"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "config" in bad.stderr
