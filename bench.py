@@ -46,8 +46,8 @@ def parse():
                          "stepwise: one nvl_forward per step with the token round trip through the host")
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-prompt", type=int, default=8)
-    ap.add_argument("--cpu-gen", type=int, default=4)
+    ap.add_argument("--cpu-prompt", type=int, default=24)
+    ap.add_argument("--cpu-gen", type=int, default=8)
     ap.add_argument("--tp", action="store_true", help="all ranks form ONE tensor-parallel group (RCCL all-reduce) "
                     "and process the same batch: strong scaling, e.g. --model llama-3-8b --gpus 8 --tp")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
