@@ -114,3 +114,39 @@ def test_native_config_loader_matches_python_mirror(pkg, tmp_path):
     bad.write_text("{\"a\": [1, 2,")
     assert L.lib().nvl_load_config_json(str(bad).encode(), C.byref(L.ModelConfigC())) < 0
     assert L.lib().nvl_load_config_json(str(tmp_path / "missing.json").encode(), C.byref(L.ModelConfigC())) < 0
+
+
+def test_block_manager_mirror_meets_the_references_own_test_expectations(pkg):
+    """tests/block_manager_mirror.py (the restatement that produces the block tables of the paged-KV GPU tests) against
+    the scenarios and expected values of the reference's own nanovllm/block_manager_test.go:7-129 and
+    sequence_test.go:53-78 (block arithmetic)."""
+    from block_manager_mirror import BlockManager
+    Sequence = pkg.Sequence
+    bm = BlockManager(100, 256)                                   # TestBlockManagerCreation
+    assert len(bm.blocks) == 100 and len(bm.free) == 100 and bm.block_size == 256
+    seq = Sequence(seq_id=0, token_ids=list(range(300)))          # TestBlockManagerAllocate: 300 tokens -> 2 blocks
+    assert bm.can_allocate(seq)
+    bm.allocate(seq)
+    assert len(seq.block_table) == 2 and len(bm.free) == 98
+    bm.deallocate(seq)                                            # TestBlockManagerDeallocate
+    assert seq.block_table == [] and len(bm.free) == 100 and seq.num_cached_tokens == 0
+    bm = BlockManager(100, 256)                                   # TestBlockManagerPrefixCaching: same 256 tokens twice
+    s1, s2 = Sequence(seq_id=1, token_ids=list(range(256))), Sequence(seq_id=2, token_ids=list(range(256)))
+    bm.allocate(s1)
+    free_first = len(bm.free)
+    bm.allocate(s2)
+    assert s2.num_cached_tokens == 256 and s2.block_table == s1.block_table and len(bm.free) == free_first
+    assert bm.blocks[s1.block_table[0]].ref_count == 2
+    h1, h2 = bm.compute_hash([1, 2, 3, 4, 5], 0), bm.compute_hash([1, 2, 3, 4, 5], 0)   # TestBlockManagerComputeHash
+    assert h1 == h2 and h1 != bm.compute_hash([1, 2, 3, 4, 6], 0)
+    assert h1 != bm.compute_hash([1, 2, 3, 4, 5], 77)             # the prefix hash chains in (block_manager.go:74-78)
+    seq = Sequence(seq_id=3, token_ids=list(range(600)))          # TestSequenceBlocks: 600 tokens -> 3 blocks, last of 88
+    assert bm.num_blocks(seq) == 3 and 600 - 2 * 256 == 88
+    # MayAppend (block_manager.go:231-263): a new block exactly when the appended token is the first of a block
+    bm = BlockManager(8, 256)
+    seq = Sequence(seq_id=4, token_ids=list(range(255)))
+    bm.allocate(seq)
+    seq.append_token(1); bm.may_append(seq)                       # 256 tokens: block full -> hashed, no new block
+    assert len(seq.block_table) == 1 and bm.blocks[seq.block_table[0]].hash != 0
+    seq.append_token(2); bm.may_append(seq)                       # 257 tokens: second block
+    assert len(seq.block_table) == 2
