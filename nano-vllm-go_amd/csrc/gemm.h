@@ -402,13 +402,15 @@ void gemm_bf16_kernel(GemmArgs p) {
 // after its last readers retired their ds_reads before the barrier that ended L(s-1) of the LATE group (WAR);
 // stage s+1 is waited for at the end of L(s) by every wave, one barrier before the early group reads it (RAW).
 // ------------------------------------------------------------------------------------------
-template <int EPI, typename OutT, int STAGES = 4, int PRIO = 0, int WAVES_N = 4>
+template <int EPI, typename OutT, int STAGES = 4, int PRIO = 0, int WAVES_N = 4, int BN = 256>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmArgs p) {
-    // WAVES_N = 4: wave tile 128x64 (a head of 64 per wave); WAVES_N = 2: wave tile 64x128 (a head of 128 per wave)
-    constexpr int BM = 256, BN = 256, WAVES_M = 8 / WAVES_N, TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
+    // BN 256: WAVES_N = 4 -> wave tile 128x64 (a head of 64 per wave), WAVES_N = 2 -> 64x128 (a head of 128 per wave);
+    // BN 128 (mid-size M: twice the tiles): WAVES_N = 2 -> wave tile 64x64
+    constexpr int BM = 256, WAVES_M = 8 / WAVES_N, TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
     constexpr int NA = BM / 16, NB = BN / 16;            // 1-KiB blocks per stage (one k-step)
-    constexpr int PW = (NA + NB) / 8;                    // 4 blocks per wave per stage
-    constexpr int STAGE_BYTES = (BM + BN) * 32 * 2;      // 32 KiB
+    constexpr int PW = (NA + NB) / 8;                    // blocks per wave per stage: 4 (BN 256) or 3 (BN 128)
+    constexpr int STAGE_BYTES = (BM + BN) * 32 * 2;      // 32 KiB / 24 KiB
+    static_assert((NA + NB) % 8 == 0, "stage blocks must divide over the 8 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -455,12 +457,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmArgs p) {
     // stage 0 landed (my part); up to STAGES-2 younger stages stay in flight
     auto wait_younger = [&](int younger) {
         if (younger > STAGES - 2) younger = STAGES - 2;
-        if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (PW == 4) {
+            if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (younger >= 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     };
-    static_assert(STAGES >= 3 && STAGES <= 5, "vmcnt immediates above cover up to three stages in flight");
+    static_assert(STAGES >= 3 && STAGES <= 5 && (PW == 4 || PW == 3), "vmcnt immediates above cover up to three stages in flight");
     wait_younger((nt < STAGES - 1 ? nt : STAGES - 1) - 1);
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();         // the late group: one phase behind from here on
@@ -948,7 +957,7 @@ static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
     if constexpr (EPI == EPI_QKV) {
         if (a.qkv.hd == 128) {     // a wave must own a whole 128-column head: 256x256 tile as 4x2 waves of 64x128
             const int t3 = cdiv(a.M, 256) * cdiv(a.N, 256);
-            if (g_force_tile == 0 && t3 >= 256 && cu_fill(t3, 1) >= 0.74 && a.K >= 160 && !a.seg && !a.a_rows) {
+            if (g_force_tile == 0 && t3 >= 192 && cu_fill(t3, 1) >= 0.74 && a.K >= 160 && !a.seg && !a.a_rows) {
                 static bool attr = false;     // the ping-pong form, wave tile 64x128
                 if (!attr) {
                     (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI, OutT, 4, 0, 2>,
@@ -966,9 +975,11 @@ static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
     if (tile == 0) {
         tile = 1;
         if (!a.seg && a.K >= 128) {
-            const int t3 = cdiv(a.M, 256) * cdiv(a.N, 256), t2 = cdiv(a.M, 256) * cdiv(a.N, 128);
-            if (t3 >= 256 && cu_fill(t3, 1) >= 0.74) tile = (!a.seg && !a.a_rows && a.K >= 160) ? 5 : 3;   // 5: ping-pong form
-            else if (t2 >= 256 && cu_fill(t2, 1) >= 0.74) tile = 2;
+            // r01 sweeps (profiles/r01e_gemm_sweep_mid.txt): the ping-pong 256x256 form wins as soon as its tiles cover
+            // 3/4 of the CUs; below that the 128x128 form (2 workgroups per CU) does; the lock-step 256-wide forms and a
+            // ping-pong 256x128 variant (wave tile 64x64: 8 fragment reads per 16 MFMAs) never do
+            const int t3 = cdiv(a.M, 256) * cdiv(a.N, 256);
+            if (t3 >= 192 && cu_fill(t3, 1) >= 0.74) tile = (!a.seg && !a.a_rows && a.K >= 160) ? 5 : 3;   // 5: ping-pong form
         }
     }
 #define NVL_PP(TILE, ST, PR)                                                                                          \
