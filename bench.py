@@ -41,9 +41,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="sequences per GPU")
     ap.add_argument("--prompt", type=int, default=512, help="prompt tokens per sequence")
     ap.add_argument("--gen", type=int, default=128, help="decode steps per sequence")
-    ap.add_argument("--decode", choices=["fused", "stepwise"], default="fused",
+    ap.add_argument("--decode", choices=["fused", "stepwise", "sampled"], default="fused",
                     help="fused: the G greedy steps in one nvl_decode_greedy call (token feedback on the device); "
-                         "stepwise: one nvl_forward per step with the token round trip through the host")
+                         "stepwise: one nvl_forward per step with the token round trip through the host; "
+                         "sampled: nvl_decode_sampled — the reference runner's default SampleWithHistory(T 1, p 1, k 0, "
+                         "repetition penalty 1.2) on the device each step instead of the argmax")
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-prompt", type=int, default=24)
@@ -192,6 +194,7 @@ def main():
     prompts = rng.integers(0, cfg["vocab_size"], (B, S)).astype(np.int32)
     seq_ids = list(range(B))
     seqs_per_call = max(1, max_batch_tokens // S)
+    sample_u = rng.random((G, B)).astype(np.float32)
 
     def one_step(profile_prefill: bool):
         """prefill all B prompts, then G decode steps; returns (prefill_s, decode_s)."""
@@ -209,6 +212,9 @@ def main():
         t_b = time.perf_counter()
         if args.decode == "fused":
             model.decode_greedy(seq_ids, nxt, G)
+        elif args.decode == "sampled":
+            hist = [np.concatenate([prompts[i], nxt[i:i + 1]]) for i in range(B)]
+            model.decode_sampled(seq_ids, nxt, G, hist, sample_u)
         else:
             for g in range(G):
                 _, am = model.forward_batch(seq_ids, [[int(t)] for t in nxt], [S + g] * B, want_logits=False)

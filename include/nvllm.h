@@ -266,6 +266,14 @@ typedef struct nvl_sampling_params {
  * float rounding of a CDF step (tests/test_sampling_gpu.py states the bound). */
 int nvl_sample(nvl_model* m, int n_rows, const nvl_sampling_params* params, const int32_t* const* history_ptrs,
                const int32_t* history_lens, const float* uniforms, int32_t* out_tokens);
+/* The decode loop of a sampling runner as ONE call (nvl_decode_greedy with SampleWithHistory instead of the argmax): each
+ * of the n_steps steps samples one id per sequence on the device from the step's logits and the sequence's history
+ * (Sequence.TokenIDs: history_ptrs/lens give it as the first step sees it, the sampled ids are appended on the device)
+ * and feeds it back.  uniforms is [n_steps][n_seqs]: the rand.Float32() draws in the order the host's serial loop over
+ * sequences (tensor_model_runner.go:58) would make them.  out_tokens [n_steps][n_seqs].  bf16 slab mode. */
+int nvl_decode_sampled(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* first_tokens, int n_steps,
+                       const nvl_sampling_params* params, const int32_t* const* history_ptrs, const int32_t* history_lens,
+                       const float* uniforms, int32_t* out_tokens);
 /* TensorModelRunner.Run including its sampling step (tensor_model_runner.go:55-97): nvl_runner_run, then
  * SampleWithHistory(lastTokenLogits, seq.TokenIDs, defaultSampling) per sequence on the device. */
 int nvl_runner_run_sampled(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* const* token_ptrs,

@@ -121,6 +121,7 @@ def lib():
     L.nvl_get_hidden.argtypes = [vp, C.c_int, vp, i64]
     L.nvl_get_kv.argtypes = [vp, i64, C.c_int, vp, vp]
     L.nvl_runner_run.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp]
+    L.nvl_decode_sampled.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(SamplingParamsC), vp, vp, vp, vp]
     L.nvl_sample.argtypes = [vp, C.c_int, C.POINTER(SamplingParamsC), vp, vp, vp, vp]
     L.nvl_runner_run_sampled.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(SamplingParamsC), vp, vp]
     L.nvl_op_sample.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.POINTER(SamplingParamsC), vp, vp, vp, vp, vp]

@@ -351,6 +351,13 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restric
     if (threadIdx.x == 0) out[r] = (bi == 0x7fffffff) ? 0 : bi;   // all -inf / NaN: reference returns index 0
 }
 
+// logits /= LogitsScaling (generic_model.go:472-477) for the rows a sampler reads (the argmax path folds it into
+// argmax_partial_kernel)
+__global__ void scale_rows_kernel(float* __restrict__ x, int ld, int n, float div) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) { float* p = x + (int64_t)blockIdx.y * ld + j; *p = *p / div; }
+}
+
 // ---------------------------------------------------------------------------------------
 // Decode seam (nvl_decode_greedy, bf16 path): the tail of step s and the head of step s+1 as ONE launch, one
 // 256-thread block per sequence: argmax over the chunk partials (argmax_final_kernel), the token fed back + every
@@ -358,7 +365,9 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restric
 // generic_model.go:567-592) and layer 0's norm of the row (norm_row_kernel) — same arithmetic, same summation order.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void decode_seam_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
-                                                          int chunks, int32_t* __restrict__ argmax_out,
+                                                          int chunks, const int32_t* __restrict__ sampled,
+                                                          int32_t* __restrict__ hist, int64_t hist_stride,
+                                                          int32_t* __restrict__ hist_len, int32_t* __restrict__ argmax_out,
                                                           int32_t* __restrict__ ring_out, int32_t* __restrict__ tokens,
                                                           int32_t* __restrict__ tok_pos, int32_t* __restrict__ seq_pos,
                                                           const bf16_t* __restrict__ emb, const bf16_t* __restrict__ pos_emb,
@@ -371,11 +380,19 @@ __global__ __launch_bounds__(256) void decode_seam_kernel(const float* __restric
     if (threadIdx.x < 64) {
         float best = -INFINITY;
         int bi = 0x7fffffff;
-        for (int c = threadIdx.x; c < chunks; c += 64) argmax_merge(best, bi, pval[r * chunks + c], pidx[r * chunks + c]);
+        if (!sampled) {
+            for (int c = threadIdx.x; c < chunks; c += 64) argmax_merge(best, bi, pval[r * chunks + c], pidx[r * chunks + c]);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) argmax_merge(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
+            for (int o = 32; o > 0; o >>= 1) argmax_merge(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
+        }
         if (threadIdx.x == 0) {
-            const int t = (bi == 0x7fffffff) ? 0 : bi;
+            int t = (bi == 0x7fffffff) ? 0 : bi;
+            if (sampled) {                 // the token comes from sample_row_kernel; it joins the sequence's history
+                t = sampled[r];
+                const int n = hist_len[r];
+                hist[(int64_t)r * hist_stride + n] = t;
+                hist_len[r] = n + 1;
+            }
             const int pos = tok_pos[r] + 1;
             argmax_out[r] = t; ring_out[r] = t; tokens[r] = t;
             tok_pos[r] = pos; seq_pos[r] = pos;          // (one token per sequence: row r IS sequence r)

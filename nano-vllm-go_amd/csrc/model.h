@@ -113,6 +113,8 @@ struct nvl_model {
     // per-call metadata (one pinned host block mirrored on the device)
     int32_t* meta_host = nullptr; int32_t* meta_dev = nullptr; int64_t meta_ints = 0;
     SampleBufs samp;             // nvl_sample scratch
+    int32_t* samp_hist = nullptr; int32_t* samp_hist_len = nullptr; int64_t samp_hist_cap = 0;   // nvl_decode_sampled: device-kept histories
+    float* samp_u_steps = nullptr; int64_t samp_u_cap = 0;
     int last_rows = 0;           // logits rows the last forward left in `logits`
     int32_t* ring = nullptr; int64_t ring_ints = 0;   // nvl_decode_greedy: [steps][seqs] tokens on the device
     // debug

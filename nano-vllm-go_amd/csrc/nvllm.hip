@@ -243,6 +243,7 @@ extern "C" void nvl_destroy(nvl_model* m) {
     dfree(m->expert_w); dfree(m->seg_start); dfree(m->moe_counts); dfree(m->moe_cursor); dfree(m->moe_tile_map); dfree(m->moe_n_mtiles); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo);
     dfree(m->meta_dev); dfree(m->hidden); dfree(m->sk_part); dfree(m->tp_part); dfree(m->ring); dfree(m->rs_part);
     free_sample_bufs(m->samp);
+    dfree(m->samp_hist); dfree(m->samp_hist_len); dfree(m->samp_u_steps);
     if (m->tp_comm) (void)ncclCommDestroy((ncclComm_t)m->tp_comm);
     if (m->tp_local) {
         bool last;
@@ -1040,7 +1041,8 @@ namespace {
 // Enqueue ONE forward pass (embedding ... argmax) on the model's stream for the batch described by the device
 // metadata `md` — no host synchronisation.  Returns the number of logits rows produced.
 // seam: 0 = whole pass; bit 0 = x and layer 0's normed operand are already in place (skip embed + first norm);
-// bit 1 = stop after the argmax partials (the caller's decode_seam_kernel finishes the step)
+// bit 1 = stop after the argmax partials (the caller's decode_seam_kernel finishes the step); bit 2 = no argmax at
+// all (the caller samples from the logits)
 int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len, double attn_flops, uint32_t flags,
                     int seam = 0) {
     const nvl_model_config& c = m->cfg;
@@ -1156,7 +1158,14 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
         if (m->pending_slices != 0) throw std::runtime_error("forward: a split-K residual was left unconsumed");
         gemm(m, EPI_STORE, true, mk(m->xn_last, H, m->lm_head, m->logits, m->Vpad, nullptr, 1.f, rows, m->V, H));
     }
-    {
+    if (seam & 4) {      // sampling reads the logits: apply LogitsScaling here (argmax_partial_kernel does it otherwise)
+        if (c.logits_scaling != 0.f) {
+            KScope ks(m, KC_OTHER);
+            hipLaunchKernelGGL(scale_rows_kernel, dim3(cdiv(m->V, 256), rows), dim3(256), 0, m->stream, m->logits, m->Vpad, m->V,
+                               c.logits_scaling);
+            NVL_HIP(hipGetLastError());
+        }
+    } else {
         KScope ks(m, KC_OTHER);
         launch_argmax(m->stream, m->logits, m->Vpad, m->V, rows, c.logits_scaling, m->argmax_pval, m->argmax_pidx,
                       (seam & 2) ? nullptr : m->argmax_dev);
@@ -1391,7 +1400,11 @@ extern "C" int nvl_runner_run_paged(nvl_model* m, int n_seqs, const int32_t* con
 namespace {
 // the n_steps decode passes of nvl_decode_greedy[_paged]: metadata for step 0 is in meta_host (one token per sequence),
 // every later step's tokens / positions are produced on the device
-void decode_loop(nvl_model* m, const Meta& hm, int n_seqs, int n_steps, int32_t* out_tokens) {
+// `sp` != NULL: every step samples (tensor.SampleWithHistory, sample.h) instead of taking the argmax; the histories live
+// on the device (m->samp_hist, one row of max_seq_len ids per sequence) and grow by the sampled token each step;
+// `uniforms_dev` is [n_steps][n_seqs]
+void decode_loop(nvl_model* m, const Meta& hm, int n_seqs, int n_steps, int32_t* out_tokens,
+                 const nvl_sampling_params* sp = nullptr, const float* uniforms_dev = nullptr) {
     const int M = n_seqs;
     const int32_t* h_pos = hm.seq_pos;
     const Meta md = bind_meta(m, m->meta_dev, M);
@@ -1409,14 +1422,25 @@ void decode_loop(nvl_model* m, const Meta& hm, int n_seqs, int n_steps, int32_t*
         for (int i = 0; i < n_seqs; i++) attn_flops += 4.0 * m->hd * m->nH * (double)(h_pos[i] + s + 1);
         // bf16 path: the step's tail (argmax, token feedback) and the next step's head (embedding gather + layer 0's
         // norm) are one launch (decode_seam_kernel); fp32 parity mode keeps the separate kernels
-        const bool seam_ok = g_decode_seam && !m->f32 && m->H <= 1024 * NORM_ROW_MAXCH && m->H % 4 == 0;
-        enqueue_forward(m, md, n_seqs, M, 1, attn_flops, 0, seam_ok ? ((s > 0 ? 1 : 0) | 2) : 0);
+        const bool seam_ok = (g_decode_seam || sp) && !m->f32 && m->H <= 1024 * NORM_ROW_MAXCH && m->H % 4 == 0;
+        if (sp && !seam_ok) throw std::runtime_error("sampled decode loop: bf16 models only");
+        enqueue_forward(m, md, n_seqs, M, 1, attn_flops, 0, seam_ok ? ((s > 0 ? 1 : 0) | (sp ? 4 : 2)) : 0);
+        if (sp) {
+            SampleArgs a{};
+            a.logits = m->logits; a.ld = m->Vpad; a.work = m->samp.work; a.cnt = m->samp.cnt; a.hist = m->samp_hist;
+            a.hist_off = nullptr; a.hist_stride = m->cfg.max_seq_len; a.hist_len = m->samp_hist_len;
+            a.uniforms = uniforms_dev + (int64_t)s * n_seqs; a.out = m->samp.out; a.probs_out = nullptr; a.ldp = m->V;
+            a.V = m->V; a.top_k = sp->top_k; a.temperature = sp->temperature; a.top_p = sp->top_p; a.rep_penalty = sp->repetition_penalty;
+            hipLaunchKernelGGL(sample_row_kernel, dim3(n_seqs), dim3(SAMPLE_THREADS), 0, m->stream, a);
+            NVL_HIP(hipGetLastError());
+        }
         if (seam_ok) {
             const void* pe = (m->cfg.position_type == NVL_POS_LEARNED) ? m->g[NVL_T_POS_EMB].p : nullptr;
             const int pe_rows = pe ? (int)std::min<int64_t>(m->g[NVL_T_POS_EMB].rows, m->cfg.max_seq_len) : 0;
             const LayerW& l0 = m->layers[0];
             hipLaunchKernelGGL(decode_seam_kernel, dim3(n_seqs), dim3(256), 0, m->stream, m->argmax_pval, m->argmax_pidx,
-                               cdiv(m->V, ARGMAX_CHUNK), m->argmax_dev, m->ring + (int64_t)s * n_seqs, md.tokens, md.tok_pos,
+                               cdiv(m->V, ARGMAX_CHUNK), sp ? (const int32_t*)m->samp.out : (const int32_t*)nullptr, m->samp_hist,
+                               (int64_t)m->cfg.max_seq_len, m->samp_hist_len, m->argmax_dev, m->ring + (int64_t)s * n_seqs, md.tokens, md.tok_pos,
                                md.seq_pos, (const bf16_t*)m->g[NVL_T_TOK_EMB].p, (const bf16_t*)pe, pe_rows,
                                m->cfg.embedding_multiplier, m->x, (const float*)l0.t[NVL_T_ATTN_NORM_W].p,
                                (const float*)l0.t[NVL_T_ATTN_NORM_B].p, m->cfg.norm_eps, (bf16_t*)m->xn, m->H);
@@ -1507,6 +1531,83 @@ extern "C" int nvl_decode_greedy_paged(nvl_model* m, int n_seqs, const int32_t* 
         hm.tokens[i] = first_tokens[i]; hm.tok_pos[i] = pos; hm.tok_tbl[i] = tb;
     }
     decode_loop(m, hm, n_seqs, n_steps, out_tokens);
+    return NVL_OK;
+    NVL_CATCH(m)
+}
+
+// nvl_decode_greedy with the reference runner's sampling step instead of the argmax (tensor_model_runner.go:89-93):
+// every step draws SampleWithHistory(logits, seq.TokenIDs, params) on the device and feeds the token back.
+// history_ptrs[i]/history_lens[i] = Sequence.TokenIDs as the first decode step sees it (prompt + the token sampled from
+// the prefill = first_tokens[i]); uniforms is [n_steps][n_seqs] (one rand.Float32() per sequence per step, in the
+// order the host's serial loop would draw them).
+extern "C" int nvl_decode_sampled(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* first_tokens, int n_steps,
+                                  const nvl_sampling_params* params, const int32_t* const* history_ptrs,
+                                  const int32_t* history_lens, const float* uniforms, int32_t* out_tokens) {
+    if (!m) return NVL_ERR_INVALID;
+    if (!m->finalized) return fail(m, NVL_ERR_STATE, "nvl_decode_sampled: model not finalized");
+    if (m->paged) return fail(m, NVL_ERR_STATE, "nvl_decode_sampled: not available in paged-KV mode");
+    if (m->f32) return fail(m, NVL_ERR_STATE, "nvl_decode_sampled: bf16 models only");
+    if (n_seqs <= 0 || n_steps <= 0 || !seq_ids || !first_tokens || !params || !history_ptrs || !history_lens || !uniforms || !out_tokens)
+        return fail(m, NVL_ERR_INVALID, "nvl_decode_sampled: null/empty arguments");
+    if (n_seqs > m->opts.max_seqs || n_seqs > m->opts.max_batch_tokens)
+        return fail(m, NVL_ERR_INVALID, "nvl_decode_sampled: n_seqs exceeds max_seqs / max_batch_tokens");
+    if (params->repetition_penalty == 0.f || !(params->repetition_penalty == params->repetition_penalty) ||
+        !(params->temperature == params->temperature) || !(params->top_p == params->top_p))
+        return fail(m, NVL_ERR_INVALID, "nvl_decode_sampled: bad sampling parameters");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    const int M = n_seqs, T = m->cfg.max_seq_len;
+    const Meta hm = bind_meta(m, m->meta_host, M);
+    std::vector<int> h_slot((size_t)n_seqs);
+    std::vector<int32_t> hist((size_t)n_seqs * T, 0), hlen((size_t)n_seqs);
+    for (int i = 0; i < n_seqs; i++) {
+        auto it = m->seq_slot.find(seq_ids[i]);
+        if (it == m->seq_slot.end()) return fail(m, NVL_ERR_UNKNOWN_SEQ, "nvl_decode_sampled: sequence has no KV slot");
+        for (int j = 0; j < i; j++) if (seq_ids[j] == seq_ids[i]) return fail(m, NVL_ERR_INVALID, "nvl_decode_sampled: duplicate sequence");
+        const int slot = it->second, pos = m->slot_len[(size_t)slot];
+        if (pos + n_steps > T) return fail(m, NVL_ERR_POSITION, "nvl_decode_sampled: position exceeds max_seq_len");
+        if (first_tokens[i] < 0 || first_tokens[i] >= m->V) return fail(m, NVL_ERR_INVALID, "nvl_decode_sampled: token id out of range");
+        const int hn = history_lens[i];
+        if (hn < 0 || hn + n_steps > T || (hn > 0 && !history_ptrs[i])) return fail(m, NVL_ERR_INVALID, "nvl_decode_sampled: history longer than max_seq_len");
+        for (int j = 0; j < hn; j++) {
+            if (history_ptrs[i][j] < 0) return fail(m, NVL_ERR_INVALID, "nvl_decode_sampled: negative token id in the history");
+            hist[(size_t)i * T + j] = history_ptrs[i][j];
+        }
+        hlen[(size_t)i] = hn;
+        hm.seq_tok_start[i] = i; hm.seq_len[i] = 1; hm.seq_pos[i] = pos; h_slot[(size_t)i] = slot; hm.last_rows[i] = i;
+        hm.seq_tbl[i] = i; hm.blk_table[i] = slot;
+        hm.tokens[i] = first_tokens[i]; hm.tok_pos[i] = pos; hm.tok_tbl[i] = i;
+    }
+    for (int64_t i = 0; i < (int64_t)n_steps * n_seqs; i++)
+        if (!(uniforms[i] >= 0.f && uniforms[i] <= 1.f)) return fail(m, NVL_ERR_INVALID, "nvl_decode_sampled: uniform draw outside [0, 1]");
+    // device state of the sampler
+    SampleBufs& b = m->samp;
+    const int64_t elems = (int64_t)n_seqs * round_up(m->V, 4);
+    if (elems > b.elems) {
+        dfree(b.work); dfree(b.cnt);
+        b.work = dmalloc<float>(elems); b.cnt = dmalloc<int32_t>(elems); b.elems = elems;
+        NVL_HIP(hipMemsetAsync(b.cnt, 0, (size_t)elems * 4, m->stream));
+    }
+    if (n_seqs > b.rows_cap) {
+        dfree(b.off); dfree(b.out); dfree(b.u);
+        b.rows_cap = (int)round_up(n_seqs, 64);
+        b.off = dmalloc<int32_t>(b.rows_cap + 1); b.out = dmalloc<int32_t>(b.rows_cap); b.u = dmalloc<float>(b.rows_cap);
+    }
+    if ((int64_t)n_seqs * T > m->samp_hist_cap) {
+        dfree(m->samp_hist); dfree(m->samp_hist_len);
+        m->samp_hist_cap = (int64_t)m->opts.max_seqs * T;
+        m->samp_hist = dmalloc<int32_t>(m->samp_hist_cap); m->samp_hist_len = dmalloc<int32_t>(m->opts.max_seqs);
+    }
+    if ((int64_t)n_steps * n_seqs > m->samp_u_cap) {
+        dfree(m->samp_u_steps);
+        m->samp_u_cap = (int64_t)n_steps * n_seqs;
+        m->samp_u_steps = dmalloc<float>(m->samp_u_cap);
+    }
+    NVL_HIP(hipMemcpyAsync(m->samp_hist, hist.data(), hist.size() * 4, hipMemcpyHostToDevice, m->stream));
+    NVL_HIP(hipMemcpyAsync(m->samp_hist_len, hlen.data(), hlen.size() * 4, hipMemcpyHostToDevice, m->stream));
+    NVL_HIP(hipMemcpyAsync(m->samp_u_steps, uniforms, (size_t)n_steps * n_seqs * 4, hipMemcpyHostToDevice, m->stream));
+    decode_loop(m, hm, n_seqs, n_steps, out_tokens, params, m->samp_u_steps);   // (synchronises: the host vectors stay alive)
+    for (int i = 0; i < n_seqs; i++) m->slot_len[(size_t)h_slot[(size_t)i]] += n_steps;
     return NVL_OK;
     NVL_CATCH(m)
 }
@@ -1633,7 +1734,7 @@ int sample_rows(hipStream_t st, SampleBufs& b, const float* logits_dev, int64_t 
         off[(size_t)i + 1] = (int32_t)hist.size();
         if (!(uniforms[i] >= 0.f && uniforms[i] <= 1.f)) { err = "uniform draw outside [0, 1]"; return NVL_ERR_INVALID; }
     }
-    const int64_t elems = (int64_t)rows * V;
+    const int64_t elems = (int64_t)rows * round_up(V, 4);
     if (elems > b.elems) {
         dfree(b.work); dfree(b.cnt);
         b.work = dmalloc<float>(elems); b.cnt = dmalloc<int32_t>(elems); b.elems = elems;
@@ -1658,7 +1759,7 @@ int sample_rows(hipStream_t st, SampleBufs& b, const float* logits_dev, int64_t 
     hipLaunchKernelGGL(sample_row_kernel, dim3(rows), dim3(SAMPLE_THREADS), 0, st, a);
     NVL_HIP(hipGetLastError());
     NVL_HIP(hipMemcpyAsync(out_host, b.out, (size_t)rows * 4, hipMemcpyDeviceToHost, st));
-    if (probs_host) NVL_HIP(hipMemcpyAsync(probs_host, b.probs, (size_t)elems * 4, hipMemcpyDeviceToHost, st));
+    if (probs_host) NVL_HIP(hipMemcpyAsync(probs_host, b.probs, (size_t)rows * V * 4, hipMemcpyDeviceToHost, st));
     NVL_HIP(hipStreamSynchronize(st));   // (also keeps the host vectors alive until the copies are done)
     return NVL_OK;
 }

@@ -16,10 +16,12 @@ namespace nvl {
 
 struct SampleArgs {
     const float* logits; int64_t ld;     // [rows][ld]: final logits (LogitsScaling already applied)
-    float* work;                          // [rows][V] scratch: the probability vector
+    float* work;                          // [rows][round_up(V, 4)] scratch: the probability vector (16-byte aligned rows)
     int32_t* cnt;                         // [rows][V] zero-filled scratch for the repetition counts; left zero-filled
     const int32_t* hist;                  // token histories, concatenated
-    const int32_t* hist_off;              // [rows + 1] offsets into hist
+    const int32_t* hist_off;              // [rows + 1] offsets into hist, or NULL:
+    int64_t hist_stride;                  //   then row r's history is hist[r * hist_stride .. + hist_len[r]) (device-kept
+    const int32_t* hist_len;              //   histories of the fused sampled decode loop)
     const float* uniforms;                // [rows] the rand.Float32() draw of each row
     int32_t* out;                         // [rows] sampled token id
     float* probs_out; int64_t ldp;        // optional [rows][ldp]: the final distribution (parity tap)
@@ -124,17 +126,38 @@ __device__ void sample_apply_threshold(float* w, int V, uint32_t T, int need, Sa
     __syncthreads();
 }
 
+// elementwise pass over a row in 16-byte pieces (the row base is 16-byte aligned: work rows have a stride of
+// round_up(V, 4) floats) plus a scalar tail: `f4` maps a float4, `f1` a float
+template <typename F4, typename F1>
+__device__ __forceinline__ void sample_for_each(float* w, int V, F4 f4, F1 f1) {
+    const int V4 = V >> 2;
+    f32x4* w4 = (f32x4*)w;
+#pragma unroll 4
+    for (int j = threadIdx.x; j < V4; j += SAMPLE_THREADS) w4[j] = f4(w4[j]);
+    for (int j = (V4 << 2) + threadIdx.x; j < V; j += SAMPLE_THREADS) w[j] = f1(w[j]);
+}
+
 __global__ __launch_bounds__(SAMPLE_THREADS) void sample_row_kernel(SampleArgs a) {
     __shared__ SampleShared sh;
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int V = a.V;
     const float* lg = a.logits + (int64_t)row * a.ld;
-    float* w = a.work + (int64_t)row * V;
+    float* w = a.work + (int64_t)row * ((V + 3) & ~3);
     int32_t* cnt = a.cnt + (int64_t)row * V;
 
     // ---- copy + repetition penalty (sampling.go:43-68): count x3 for the last 10 history tokens ----
-    for (int j = tid; j < V; j += SAMPLE_THREADS) w[j] = lg[j];
-    const int h0 = a.hist_off[row], hn = a.hist_off[row + 1] - h0;
+    if ((a.ld & 3) == 0) {
+        const f32x4* lg4 = (const f32x4*)lg;
+        f32x4* w4 = (f32x4*)w;
+#pragma unroll 4
+        for (int j = tid; j < (V >> 2); j += SAMPLE_THREADS) w4[j] = lg4[j];
+        for (int j = (V & ~3) + tid; j < V; j += SAMPLE_THREADS) w[j] = lg[j];
+    } else {
+#pragma unroll 8
+        for (int j = tid; j < V; j += SAMPLE_THREADS) w[j] = lg[j];
+    }
+    const int64_t h0 = a.hist_off ? (int64_t)a.hist_off[row] : (int64_t)row * a.hist_stride;
+    const int hn = a.hist_off ? a.hist_off[row + 1] - a.hist_off[row] : a.hist_len[row];
     if (a.rep_penalty != 1.0f && hn > 0) {
         for (int i = tid; i < hn; i += SAMPLE_THREADS) {
             const int t = a.hist[h0 + i];
@@ -154,23 +177,24 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_row_kernel(SampleArgs a
     }
     __syncthreads();
 
-    // ---- temperature (:71-75) and softmax (:105-127: exp in float64, narrowed) ----
+    // ---- temperature (:71-75) and softmax (:105-127) ----
     const bool scale = a.temperature > 0.f && a.temperature != 1.0f;
+    const float temp = a.temperature;
     float mx = -INFINITY;
-    for (int j = tid; j < V; j += SAMPLE_THREADS) {
-        float l = w[j];
-        if (scale) { l = l / a.temperature; w[j] = l; }
-        mx = fmaxf(mx, l);
-    }
+    sample_for_each(w, V,
+        [&](f32x4 v) { if (scale) v = f32x4{v[0] / temp, v[1] / temp, v[2] / temp, v[3] / temp};
+                       mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3])); return v; },
+        [&](float v) { if (scale) v = v / temp; mx = fmaxf(mx, v); return v; });
     mx = sample_block_max(mx, sh);
     float part = 0.f;
-    for (int j = tid; j < V; j += SAMPLE_THREADS) {
-        const float e = (float)exp((double)(w[j] - mx));
-        w[j] = e;
-        part += e;
-    }
+    // (the reference narrows a float64 exp: <= 1 ulp from expf, far inside the tolerance)
+    sample_for_each(w, V,
+        [&](f32x4 v) { v = f32x4{expf(v[0] - mx), expf(v[1] - mx), expf(v[2] - mx), expf(v[3] - mx)};
+                       part += (v[0] + v[1]) + (v[2] + v[3]); return v; },
+        [&](float v) { v = expf(v - mx); part += v; return v; });
     const float denom = sample_block_sum(part, sh);
-    for (int j = tid; j < V; j += SAMPLE_THREADS) w[j] = w[j] / denom;
+    sample_for_each(w, V, [&](f32x4 v) { return f32x4{v[0] / denom, v[1] / denom, v[2] / denom, v[3] / denom}; },
+                    [&](float v) { return v / denom; });
     __syncthreads();
 
     // ---- top-k (:78-80, :130-156) ----
@@ -198,30 +222,44 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_row_kernel(SampleArgs a
 
     // ---- renormalise (:88-96) ----
     part = 0.f;
-    for (int j = tid; j < V; j += SAMPLE_THREADS) part += w[j];
+    sample_for_each(w, V, [&](f32x4 v) { part += (v[0] + v[1]) + (v[2] + v[3]); return v; }, [&](float v) { part += v; return v; });
     const float total = sample_block_sum(part, sh);
     if (total > 0.f)
-        for (int j = tid; j < V; j += SAMPLE_THREADS) w[j] = w[j] / total;
+        sample_for_each(w, V, [&](f32x4 v) { return f32x4{v[0] / total, v[1] / total, v[2] / total, v[3] / total}; },
+                        [&](float v) { return v / total; });
     __syncthreads();
-    if (a.probs_out)
+    if (a.probs_out) {
+#pragma unroll 8
         for (int j = tid; j < V; j += SAMPLE_THREADS) a.probs_out[(int64_t)row * a.ldp + j] = w[j];
+    }
 
     // ---- multinomial (:198-217): first index whose running sum (index order) reaches r = u * sum ----
-    const int seg = ((V + SAMPLE_WAVES - 1) / SAMPLE_WAVES + 63) & ~63;
+    // every wave owns a contiguous segment; a lane takes 4 consecutive entries per step (one 16-byte load)
+    const int seg = ((V + SAMPLE_WAVES - 1) / SAMPLE_WAVES + 255) & ~255;
     const int j0 = wave * seg, j1 = min(V, j0 + seg);
-    auto wave_scan = [&](float v) {
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const float y = __shfl_up(v, o, 64);
-            if (lane >= o) v += y;
-        }
+    auto load4 = [&](int j) {                   // entries j .. j+3 (zero beyond the segment)
+        if (j + 3 < j1) return *(const f32x4*)(w + j);
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 4; k++) if (j + k < j1) v[k] = w[j + k];
         return v;
     };
+    auto lane_scan = [&](f32x4 v, float& lane_total) {    // inclusive prefix inside the lane, then across the wave
+        v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
+        float t = v[3];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float y = __shfl_up(t, o, 64);
+            if (lane >= o) t += y;
+        }
+        lane_total = t;                                      // inclusive over lanes 0..lane
+        const float excl = t - v[3];
+        return f32x4{excl + v[0], excl + v[1], excl + v[2], excl + v[3]};
+    };
     float carry = 0.f;
-    for (int base = j0; base < j1; base += 64) {
-        const int j = base + lane;
-        const float x = wave_scan(j < j1 ? w[j] : 0.f);
-        carry += __shfl(x, 63, 64);
+    for (int base = j0; base < j1; base += 256) {
+        float t;
+        (void)lane_scan(load4(base + lane * 4), t);
+        carry += __shfl(t, 63, 64);
     }
     if (lane == 0) sh.seg_sum[wave] = carry;
     if (tid == 0) sh.idx = 0x7fffffff;
@@ -233,15 +271,19 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_row_kernel(SampleArgs a
     }
     const float r = a.uniforms[row] * grand;
     carry = off;
-    for (int base = j0; base < j1; base += 64) {
-        const int j = base + lane;
-        const float x = wave_scan(j < j1 ? w[j] : 0.f);
-        const unsigned long long hit = __ballot(j < j1 && carry + x >= r);
+    for (int base = j0; base < j1; base += 256) {
+        const int j = base + lane * 4;
+        float t;
+        const f32x4 c = lane_scan(load4(j), t);
+        int k = 4;                                           // first of my 4 entries whose running sum reaches r
+        for (int q = 3; q >= 0; q--) if (j + q < j1 && carry + c[q] >= r) k = q;
+        const unsigned long long hit = __ballot(k < 4);
         if (hit) {
-            if (lane == 0) atomicMin(&sh.idx, base + (int)__ffsll((long long)hit) - 1);
+            const int first = (int)__ffsll((long long)hit) - 1;
+            if (lane == first) atomicMin(&sh.idx, j + k);
             break;
         }
-        carry += __shfl(x, 63, 64);
+        carry += __shfl(t, 63, 64);
     }
     __syncthreads();
     if (tid == 0) a.out[row] = sh.idx == 0x7fffffff ? V - 1 : sh.idx;

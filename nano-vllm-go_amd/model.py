@@ -228,6 +228,22 @@ class HipTransformerModel:
             out += [int(t) for t in self.decode_greedy([seq_id], [out[0]], max_tokens - 1)[:, 0]]
         return out
 
+    def decode_sampled(self, seq_ids, first_tokens, n_steps: int, histories, uniforms, *, temperature=1.0, top_p=1.0,
+                       top_k=0, repetition_penalty=1.2):
+        """nvl_decode_sampled: n_steps sampled decode steps on the device -> [n_steps, n_seqs].  histories[i] = the
+        sequence's token ids so far (ending with first_tokens[i]); uniforms [n_steps, n_seqs]."""
+        from .ops import _histories
+        n = len(seq_ids)
+        ids = np.ascontiguousarray(seq_ids, dtype=np.int64)
+        first = np.ascontiguousarray(first_tokens, dtype=np.int32)
+        ptrs, lens, keep = _histories(histories, n)
+        u = np.ascontiguousarray(uniforms, dtype=np.float32).reshape(n_steps, n)
+        out = np.empty((n_steps, n), dtype=np.int32)
+        sp = L.sampling_params(temperature, top_p, top_k, repetition_penalty)
+        L.check(self.lib.nvl_decode_sampled(self.h, n, _ptr(ids), _ptr(first), n_steps, C.byref(sp), ptrs, _ptr(lens), _ptr(u),
+                                            _ptr(out)), self.h)
+        return out
+
     def sample(self, histories, uniforms, *, temperature=1.0, top_p=1.0, top_k=0, repetition_penalty=1.2):
         """nvl_sample: tensor.SampleWithHistory on the logits rows the last forward left on the device."""
         from .ops import _histories

@@ -143,3 +143,47 @@ def test_sampling_argument_errors(gpu):
         gpu.ops.sample_with_history(lg, None, [1.5])
     with pytest.raises(gpu.NvlError):
         gpu.ops.sample_with_history(lg, None, [0.5], repetition_penalty=0.0)
+
+
+@pytest.mark.parametrize("family", ["llama", "gpt2", "granite_moe"])
+def test_fused_sampled_decode_equals_stepwise(gpu, oracle, family):
+    """nvl_decode_sampled (sample + token feedback + history append on the device, n steps in one call) == the same loop
+    driven step by step: nvl_forward, nvl_sample with the grown history, append (tensor_model_runner.go:55-97)."""
+    cfg = gpu.synth.tiny_config(family)
+    w = gpu.synth.make_weights(cfg, seed=7, scale=0.05)
+    hm = gpu.HipTransformerModel(cfg, w, precision="bf16", max_seqs=4, max_batch_tokens=256)
+    r = np.random.default_rng(31)
+    prompts = [r.integers(0, cfg["vocab_size"], n).tolist() for n in (9, 33, 2)]
+    ids, steps = [0, 1, 2], 14
+    kw = dict(temperature=0.9, top_k=50, top_p=0.95, repetition_penalty=1.2)
+    U = r.random((steps + 1, 3)).astype(np.float32)
+    # step by step through the host
+    for i in ids:
+        hm.seq_reset(i)
+    hm.forward_batch(ids, prompts, [0, 0, 0], want_logits=False)
+    hist = [list(p) for p in prompts]
+    first = hm.sample(hist, U[0], **kw)
+    for h, t in zip(hist, first):
+        h.append(int(t))
+    want = []
+    for s in range(steps):
+        hm.forward_batch(ids, [[h[-1]] for h in hist], [len(h) - 1 for h in hist], want_logits=False)
+        tok = hm.sample(hist, U[s + 1], **kw)
+        want.append(tok.copy())
+        for h, t in zip(hist, tok):
+            h.append(int(t))
+    # fused
+    for i in ids:
+        hm.seq_reset(i)
+    hm.forward_batch(ids, prompts, [0, 0, 0], want_logits=False)
+    hist2 = [list(p) for p in prompts]
+    first2 = hm.sample(hist2, U[0], **kw)
+    assert np.array_equal(first2, first)
+    for h, t in zip(hist2, first2):
+        h.append(int(t))
+    got = hm.decode_sampled(ids, first2, steps, hist2, U[1:], **kw)
+    assert np.array_equal(got, np.stack(want))
+    assert [hm.seq_len(i) for i in ids] == [len(p) + steps for p in prompts]
+    with pytest.raises(gpu.NvlError):                       # a draw outside [0, 1]
+        hm.decode_sampled(ids, got[-1], 2, [h + [0] for h in hist2], np.full((2, 3), 1.5, np.float32), **kw)
+    hm.close()
