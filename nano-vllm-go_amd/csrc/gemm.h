@@ -8,12 +8,15 @@
 // keeps weights [in,out] fp32 (generic_loader.go:398-403); nvl_upload_tensor converts once at load,
 // and every kernel that produces a GEMM input (norm, attention, SwiGLU/GELU epilogue) writes it
 // directly in this layout.
-//   * gemm_bf16_kernel   (prefill, M > 64): 128x128x64 tiles, 4 waves (2x2), each wave a 64x64
-//     sub-tile as 4x4 v_mfma_f32_16x16x32_bf16 accumulators; operand blocks go HBM->LDS with
-//     global_load_lds_dwordx4 (one contiguous KiB per wave-instruction, no VGPR round trip),
-//     double-buffered; the LDS image is lane-linear so the fragment ds_read_b128s are
-//     bank-conflict-free with no swizzle.  MFMA-bound.
-//   * gemm_skinny_bf16_kernel (decode, M <= 64): weight-streaming, HBM-bound (see below).
+//   * gemm_bf16_pp_kernel (prefill, >= 192 tiles of 256x256): the ping-pong form — two groups of four waves one phase
+//     apart, K in 32-wide stages through a 4-slot LDS ring filled by global_load_lds_dwordx4, so one group's fragment
+//     reads run beside the other's MFMAs.  MFMA-bound.
+//   * gemm_bf16_kernel (prefill, fewer tiles; MoE expert groups): lock-step tiles, by default 128x128x64 with 4 waves
+//     (2x2), each wave a 64x64 sub-tile as 4x4 v_mfma_f32_16x16x32_bf16 accumulators; operand blocks go HBM->LDS with
+//     global_load_lds_dwordx4 (one contiguous KiB per wave-instruction, no VGPR round trip), double-buffered; the LDS
+//     image is lane-linear so the fragment ds_read_b128s are bank-conflict-free with no swizzle.
+//   * gemm_skinny_bf16_kernel / gemm_skinny_wide_bf16_kernel (decode, M <= 64): weight-streaming, HBM-bound (see below);
+//     the residual projections also carry the deferred RMSNorm (GemmArgs::rs_out / rs_in).
 // The MFMA is issued "swapped" (weights as the A operand) so each lane ends up with 4 consecutive N
 // elements of one output row: 8/16-byte epilogue accesses, and the bf16 epilogues can write the
 // next GEMM's fragment-major operand directly.
