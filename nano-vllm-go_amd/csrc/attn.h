@@ -91,6 +91,10 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
 #pragma unroll
     for (int d = 0; d < DT; d++) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
+    // softmax in the exp2 domain: scores are scaled by scale * log2(e) once, so every exponential is one v_exp_f32
+    const float sl2 = p.scale * 1.4426950408889634f;
+    // first key tile that any row of this WAVE may not see completely (causal): tiles below it need no masking
+    const int wave_first_limit = pos0 + (qt * 64 + wave * 16) / p.group;
 
     for (int kt = 0; kt < n_kt; kt++) {
         // the KV block holding this 64-key tile (64 | Tmax: a tile never straddles blocks)
@@ -130,33 +134,44 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
         }
         // lane holds S^T[key = kt*64 + 16t + 4fg + r][q = fq]
         float tmax = -INFINITY;
+        if (kt * 64 + 63 <= wave_first_limit) {          // every row of the wave sees the whole tile
 #pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int key = kt * 64 + t * 16 + fg * 4 + r;
-                float v = s[t][r] * p.scale;
-                v = (key <= limit) ? v : -INFINITY;      // reference: -1e10 then exp() == 0 exactly
-                s[t][r] = v;
-                tmax = fmaxf(tmax, v);
+            for (int t = 0; t < 4; t++) {
+                s[t] *= sl2;
+                tmax = fmaxf(tmax, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
             }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int key = kt * 64 + t * 16 + fg * 4 + r;
+                    float v = s[t][r] * sl2;
+                    v = (key <= limit) ? v : -INFINITY;      // reference: -1e10 then exp() == 0 exactly
+                    s[t][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+        }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);          // finite: key 0 is always visible in tile 0
-        const float alpha = __expf(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; t++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float pv = __expf(s[t][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(s[t][r] - m_new);
                 s[t][r] = pv;
                 psum += pv;
             }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
+        if (__any(m_new != m_run)) {                     // the running maximum moved for some row of the wave: rescale
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
 #pragma unroll
-        for (int d = 0; d < DT; d++) o[d] *= alpha;
+            for (int d = 0; d < DT; d++) o[d] *= alpha;
+        }
+        l_run += psum;
+        m_run = m_new;
 
         // ---- O^T += V^T · P^T : k index permuted identically on both operands ----
 #pragma unroll
