@@ -114,6 +114,79 @@ struct PendingResid {
     const int32_t* slot_of;
     const float* gate_w;
 };
+// Prefill-sized batches, bf16 output: one 1024-thread workgroup per 16 output rows (one fragment-major row tile).  A wave
+// normalises one row held in registers (same arithmetic as norm_kernel) into LDS; the workgroup then writes the tile's
+// 1-KiB operand blocks with full-line stores (norm_kernel's lanes each write 8 bytes of a block: 16-byte fragments at a
+// 256-byte stride).  H <= 64 * 4 * MAXCH (instances for 8 and 16 chunks per lane: H <= 2048 / 4096).
+template <int MAXCH>
+__global__ __launch_bounds__(1024) void norm_tile16_kernel(const float* __restrict__ x, const int32_t* __restrict__ rows_idx,
+                                                           const float* __restrict__ w, const float* __restrict__ b,
+                                                           float eps, bf16_t* __restrict__ y, int rows, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem_n[];
+    bf16_t* tile = (bf16_t*)smem_n;                       // [16][H]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 16 + wave;
+    const int H4 = H >> 2;
+    if (r < rows) {
+        const int src = rows_idx ? rows_idx[r] : r;
+        const float* xr = x + (int64_t)src * H;
+        f32x4 v[MAXCH];
+#pragma unroll
+        for (int c = 0; c < MAXCH; c++) {
+            const int j = lane + c * 64;
+            v[c] = j < H4 ? *(const f32x4*)(xr + j * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float mean = 0.f, inv;
+        if (b == nullptr) {
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXCH; c++) ss += v[c][0] * v[c][0] + v[c][1] * v[c][1] + v[c][2] * v[c][2] + v[c][3] * v[c][3];
+            inv = sqrtf(wave_sum(ss) / (float)H + eps);
+        } else {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXCH; c++) s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+            mean = wave_sum(s) / (float)H;
+            float vs = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXCH; c++) {
+                const int j = lane + c * 64;
+                if (j < H4) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const float d = v[c][k] - mean; vs += d * d; }
+                }
+            }
+            inv = sqrtf(wave_sum(vs) / (float)H + eps);
+        }
+#pragma unroll
+        for (int c = 0; c < MAXCH; c++) {
+            const int j = lane + c * 64;
+            if (j < H4) {
+                const f32x4 ww = *(const f32x4*)(w + j * 4);
+                bf16x4 o;
+                if (b == nullptr) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) o[k] = (bf16_t)((v[c][k] / inv) * ww[k]);
+                } else {
+                    const f32x4 bb = *(const f32x4*)(b + j * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) o[k] = (bf16_t)(((v[c][k] - mean) / inv) * ww[k] + bb[k]);
+                }
+                *(bf16x4*)(tile + wave * H + j * 4) = o;
+            }
+        }
+    }
+    __syncthreads();
+    // operand blocks of this row tile: block kb holds k = 32kb .. 32kb+31 of the 16 rows, lane l = row (l & 15), 8 k's (l >> 4)
+    const int nkb = H >> 5;
+    const int lr = lane & 15, lc = lane >> 4;
+    if (blockIdx.x * 16 + lr < rows)
+        for (int kb = wave; kb < nkb; kb += 16) {
+            const bf16x8 f = *(const bf16x8*)(tile + lr * H + kb * 32 + lc * 8);
+            *(bf16x8*)(y + (((int64_t)blockIdx.x * nkb + kb) * 64 + lane) * 8) = f;
+        }
+}
+
 // the arithmetic of one row once it sits in registers (shared by norm_row_kernel and decode_seam_kernel)
 template <typename ActT>
 __device__ __forceinline__ void norm_row_finish(f32x4 (&v)[NORM_ROW_MAXCH], f32x4 (&ww)[NORM_ROW_MAXCH],

@@ -768,6 +768,7 @@ Meta bind_meta(const nvl_model* m, int32_t* base, int M) {
 }
 size_t meta_bytes(const nvl_model* m, int M) { return (size_t)(5 * (int64_t)m->opts.max_seqs + m->table_cap + 3 * (int64_t)M) * 4; }
 
+static int g_norm_t16 = 1;     // nvl_set_tuning key 9: norm_tile16_kernel for prefill-sized bf16 norms (0 = norm_kernel)
 template <typename ActT>
 void launch_norm(nvl_model* m, float* x, const int32_t* rows_idx, const float* w, const float* b,
                  void* y, int rows) {
@@ -782,7 +783,22 @@ void launch_norm(nvl_model* m, float* x, const int32_t* rows_idx, const float* w
     if (rows <= 512 && m->H <= 1024 * NORM_ROW_MAXCH)
         hipLaunchKernelGGL((norm_row_kernel<ActT>), dim3(rows), dim3(256), 0, m->stream, x, rows_idx, w, b,
                            m->cfg.norm_eps, (ActT*)y, m->H, pr);
-    else
+    else if (sizeof(ActT) == 2 && m->H % 32 == 0 && m->H <= 4096 && g_norm_t16) {   // (wider rows would spill: norm_kernel)
+        // 16 rows x H bf16 of LDS (up to 160 KiB); the row sits in registers: instance by chunks per lane
+#define NVL_NT16(CH)                                                                                                   \
+        do {                                                                                                           \
+            static bool attr = false;                                                                                  \
+            if (!attr) {                                                                                               \
+                (void)hipFuncSetAttribute((const void*)norm_tile16_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          160 * 1024);                                                                 \
+                attr = true;                                                                                           \
+            }                                                                                                          \
+            hipLaunchKernelGGL(norm_tile16_kernel<CH>, dim3(cdiv(rows, 16)), dim3(1024), (size_t)16 * m->H * 2, m->stream, x, \
+                               rows_idx, w, b, m->cfg.norm_eps, (bf16_t*)y, rows, m->H);                                \
+        } while (0)
+        if (m->H <= 2048) NVL_NT16(8); else NVL_NT16(16);
+#undef NVL_NT16
+    } else
         hipLaunchKernelGGL((norm_kernel<ActT>), dim3(cdiv(rows, 4)), dim3(256), 0, m->stream, x, rows_idx, w, b,
                            m->cfg.norm_eps, (ActT*)y, rows, m->H);
 }
