@@ -51,137 +51,173 @@ struct AttnArgs {
 // index of the KV block that holds key `key`
 __device__ __forceinline__ int kv_block_index(const AttnArgs& p, int key) { return p.bs_shift >= 0 ? (key >> p.bs_shift) : key / p.Tmax; }
 
-template <int HD>
+template <int HD, int TQ>
 __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
+    // TQ = 16-row query sub-tiles per wave: every K / V^T fragment read from LDS feeds TQ MFMAs (the loop is LDS-bound at
+    // TQ = 1: 1 KiB of fragment reads per MFMA).  A workgroup covers 64 * TQ query rows.
     constexpr int KROW = HD + 8;       // bf16 elements per K tile row (padded: 144 B for HD=64)
     constexpr int VROW = 64 + 8;       // bf16 elements per V^T tile row
     constexpr int KS = HD / 32;        // k-steps of the QK^T product
     constexpr int DT = HD / 16;        // 16-row d tiles of O^T
+    constexpr int QROWS = 64 * TQ;     // query rows per workgroup
     __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * KROW];
     __shared__ __attribute__((aligned(16))) bf16_t Vts[HD * VROW];
 
     const int seq = blockIdx.z, kvh = blockIdx.y, qt = blockIdx.x;
     const int S = p.seq_len[seq];
     const int R = S * p.group;                 // query rows of this (seq, kv head)
-    if (qt * 64 >= R) return;
+    if (qt * QROWS >= R) return;
     const int tok0 = p.seq_tok_start[seq], pos0 = p.seq_pos[seq];
     const int32_t* tbl = p.blk_table + (int64_t)seq * p.tbl_stride;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fq = lane & 15, fg = lane >> 4;
 
-    // ---- this lane's query row ----
-    int row = qt * 64 + wave * 16 + fq;
-    const bool row_ok = row < R;
-    if (!row_ok) row = qt * 64;                // clamp to a valid row; result discarded
-    const int s_idx = row / p.group, hg = row - s_idx * p.group;
-    const int head = kvh * p.group + hg;
-    const int limit = pos0 + s_idx;            // last key this row may attend to (causal)
-    const bf16_t* qp = (const bf16_t*)p.q + (int64_t)(tok0 + s_idx) * p.q_stride + head * HD;
-    bf16x8 qf[KS];
+    // ---- this lane's query rows (one per sub-tile) ----
+    bool row_ok[TQ];
+    int s_idx[TQ], head[TQ], limit[TQ];
+    bf16x8 qf[TQ][KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) qf[ks] = *(const bf16x8*)(qp + ks * 32 + fg * 8);
+    for (int qi = 0; qi < TQ; qi++) {
+        int row = qt * QROWS + (wave * TQ + qi) * 16 + fq;
+        row_ok[qi] = row < R;
+        if (!row_ok[qi]) row = qt * QROWS;     // clamp to a valid row; result discarded
+        s_idx[qi] = row / p.group;
+        head[qi] = kvh * p.group + (row - s_idx[qi] * p.group);
+        limit[qi] = pos0 + s_idx[qi];          // last key this row may attend to (causal)
+        const bf16_t* qp = (const bf16_t*)p.q + (int64_t)(tok0 + s_idx[qi]) * p.q_stride + head[qi] * HD;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) qf[qi][ks] = *(const bf16x8*)(qp + ks * 32 + fg * 8);
+    }
 
     // last key any row of this workgroup needs
-    int last_row = qt * 64 + 63;
+    int last_row = qt * QROWS + QROWS - 1;
     if (last_row > R - 1) last_row = R - 1;
     const int kmax = pos0 + last_row / p.group;
     const int n_kt = kmax / 64 + 1;
 
-    f32x4 o[DT];
+    f32x4 o[TQ][DT];
+    float m_run[TQ], l_run[TQ];
 #pragma unroll
-    for (int d = 0; d < DT; d++) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int qi = 0; qi < TQ; qi++) {
+        m_run[qi] = -INFINITY; l_run[qi] = 0.f;
+#pragma unroll
+        for (int d = 0; d < DT; d++) o[qi][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // softmax in the exp2 domain: scores are scaled by scale * log2(e) once, so every exponential is one v_exp_f32
     const float sl2 = p.scale * 1.4426950408889634f;
     // first key tile that any row of this WAVE may not see completely (causal): tiles below it need no masking
-    const int wave_first_limit = pos0 + (qt * 64 + wave * 16) / p.group;
+    const int wave_first_limit = pos0 + (qt * QROWS + wave * TQ * 16) / p.group;
 
-    for (int kt = 0; kt < n_kt; kt++) {
-        // the KV block holding this 64-key tile (64 | Tmax: a tile never straddles blocks)
-        const int bi = kv_block_index(p, kt * 64), krow0 = kt * 64 - bi * p.Tmax;
+    // K/V tiles are fetched one tile ahead into registers (64 B per thread), so the global latency of tile kt+1 runs
+    // under the MFMAs and softmax of tile kt; the LDS image is refreshed between two barriers
+    constexpr int KCH = HD / 8;                      // 16-B chunks per K row
+    constexpr int KPT = 64 * KCH / 256, VPT = HD * 8 / 256;     // chunks per thread: K tile, V^T tile
+    bf16x8 kreg[KPT], vreg[VPT];
+    auto fetch = [&](int kt) {
+        const int bi = kv_block_index(p, kt * 64), krow0 = kt * 64 - bi * p.Tmax;      // (64 | Tmax: no straddling)
         const int64_t blk_off = (int64_t)tbl[bi] * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
         const bf16_t* kbase = (const bf16_t*)p.kcache + blk_off + (int64_t)krow0 * HD;     // K rows of the tile
         const bf16_t* vbase = (const bf16_t*)p.vcache + blk_off + krow0;                    // V^T columns of the tile
-        __syncthreads();
-        // ---- stage K tile [64 keys][HD] and V^T tile [HD][64 keys] (register staged) ----
-        {
-            constexpr int KCH = HD / 8;              // 16-B chunks per K row
 #pragma unroll
-            for (int c = tid; c < 64 * KCH; c += 256) {
-                const int r = c / KCH, cc = c % KCH;
-                const bf16x8 v = *(const bf16x8*)(kbase + (int64_t)r * HD + cc * 8);
-                *(bf16x8*)(Ks + r * KROW + cc * 8) = v;
-            }
-#pragma unroll
-            for (int c = tid; c < HD * 8; c += 256) {
-                const int r = c >> 3, cc = c & 7;
-                const bf16x8 v = *(const bf16x8*)(vbase + (int64_t)r * p.Tmax + cc * 8);
-                *(bf16x8*)(Vts + r * VROW + cc * 8) = v;
-            }
+        for (int i = 0; i < KPT; i++) {
+            const int c = tid + i * 256, r = c / KCH, cc = c % KCH;
+            kreg[i] = *(const bf16x8*)(kbase + (int64_t)r * HD + cc * 8);
         }
+#pragma unroll
+        for (int i = 0; i < VPT; i++) {
+            const int c = tid + i * 256, r = c >> 3, cc = c & 7;
+            vreg[i] = *(const bf16x8*)(vbase + (int64_t)r * p.Tmax + cc * 8);
+        }
+    };
+    fetch(0);
+    for (int kt = 0; kt < n_kt; kt++) {
+        __syncthreads();                             // every wave is done reading the previous tile's LDS image
+#pragma unroll
+        for (int i = 0; i < KPT; i++) {
+            const int c = tid + i * 256, r = c / KCH, cc = c % KCH;
+            *(bf16x8*)(Ks + r * KROW + cc * 8) = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; i++) {
+            const int c = tid + i * 256, r = c >> 3, cc = c & 7;
+            *(bf16x8*)(Vts + r * VROW + cc * 8) = vreg[i];
+        }
+        if (kt + 1 < n_kt) fetch(kt + 1);            // in flight during this tile's compute
         __syncthreads();
 
-        // ---- S^T = K · Q^T : 4 sub-tiles of 16 keys ----
-        f32x4 s[4];
+        // ---- S^T = K · Q^T : 4 sub-tiles of 16 keys, each K fragment used for all TQ query sub-tiles ----
+        f32x4 s[TQ][4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qi = 0; qi < TQ; qi++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) s[qi][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; t++)
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 const bf16x8 kf = *(const bf16x8*)(Ks + (t * 16 + fq) * KROW + ks * 32 + fg * 8);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
-            }
-        }
-        // lane holds S^T[key = kt*64 + 16t + 4fg + r][q = fq]
-        float tmax = -INFINITY;
-        if (kt * 64 + 63 <= wave_first_limit) {          // every row of the wave sees the whole tile
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                s[t] *= sl2;
-                tmax = fmaxf(tmax, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+                for (int qi = 0; qi < TQ; qi++)
+                    s[qi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], s[qi][t], 0, 0, 0);
             }
-        } else {
+        // lane holds S^T[key = kt*64 + 16t + 4fg + r][q = fq] per sub-tile
+        const bool whole = kt * 64 + 63 <= wave_first_limit;      // every row of the wave sees the whole tile
+#pragma unroll
+        for (int qi = 0; qi < TQ; qi++) {
+            float tmax = -INFINITY;
+            if (whole) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    s[qi][t] *= sl2;
+                    tmax = fmaxf(tmax, fmaxf(fmaxf(s[qi][t][0], s[qi][t][1]), fmaxf(s[qi][t][2], s[qi][t][3])));
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int key = kt * 64 + t * 16 + fg * 4 + r;
+                        float v = s[qi][t][r] * sl2;
+                        v = (key <= limit[qi]) ? v : -INFINITY;      // reference: -1e10 then exp() == 0 exactly
+                        s[qi][t][r] = v;
+                        tmax = fmaxf(tmax, v);
+                    }
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run[qi], tmax);
+            // a sub-tile whose rows see nothing yet (its causal limit lies before this tile AND before every earlier
+            // one) cannot occur: tile 0 always holds key 0 <= limit, so m_new is finite from the first tile on
+            float psum = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int key = kt * 64 + t * 16 + fg * 4 + r;
-                    float v = s[t][r] * sl2;
-                    v = (key <= limit) ? v : -INFINITY;      // reference: -1e10 then exp() == 0 exactly
-                    s[t][r] = v;
-                    tmax = fmaxf(tmax, v);
+                    const float pv = __builtin_amdgcn_exp2f(s[qi][t][r] - m_new);
+                    s[qi][t][r] = pv;
+                    psum += pv;
                 }
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);          // finite: key 0 is always visible in tile 0
-        float psum = 0.f;
+            if (__any(m_new != m_run[qi])) {                 // the running maximum moved for some row: rescale
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+                l_run[qi] *= alpha;
 #pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float pv = __builtin_amdgcn_exp2f(s[t][r] - m_new);
-                s[t][r] = pv;
-                psum += pv;
+                for (int d = 0; d < DT; d++) o[qi][d] *= alpha;
             }
-        if (__any(m_new != m_run)) {                     // the running maximum moved for some row of the wave: rescale
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
-#pragma unroll
-            for (int d = 0; d < DT; d++) o[d] *= alpha;
+            l_run[qi] += psum;
+            m_run[qi] = m_new;
         }
-        l_run += psum;
-        m_run = m_new;
 
-        // ---- O^T += V^T · P^T : k index permuted identically on both operands ----
+        // ---- O^T += V^T · P^T : k index permuted identically on both operands; each V^T fragment used TQ times ----
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            bf16x8 pf;
+            bf16x8 pf[TQ];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                pf[r] = (bf16_t)s[2 * u][r];          // keys 32u + 4fg + r
-                pf[4 + r] = (bf16_t)s[2 * u + 1][r];  // keys 32u + 16 + 4fg + r
-            }
+            for (int qi = 0; qi < TQ; qi++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    pf[qi][r] = (bf16_t)s[qi][2 * u][r];          // keys 32u + 4fg + r
+                    pf[qi][4 + r] = (bf16_t)s[qi][2 * u + 1][r];  // keys 32u + 16 + 4fg + r
+                }
 #pragma unroll
             for (int d = 0; d < DT; d++) {
                 const bf16_t* vr = Vts + (d * 16 + fq) * VROW + u * 32 + fg * 4;
@@ -190,18 +226,24 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
                 bf16x8 vf;
 #pragma unroll
                 for (int r = 0; r < 4; r++) { vf[r] = lo[r]; vf[4 + r] = hi[r]; }
-                o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[d], 0, 0, 0);
+#pragma unroll
+                for (int qi = 0; qi < TQ; qi++)
+                    o[qi][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qi], o[qi][d], 0, 0, 0);
             }
         }
     }
 
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
-    if (!row_ok) return;
-    const float inv = 1.0f / l_run;
 #pragma unroll
-    for (int d = 0; d < DT; d++)    // O[q][d = 16d + 4fg + r], written in the next GEMM's operand layout
-        act_store4<bf16_t>((bf16_t*)p.out, tok0 + s_idx, head * HD + d * 16 + fg * 4, p.out_stride, o[d] * inv);
+    for (int qi = 0; qi < TQ; qi++) {
+        float l = l_run[qi];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (!row_ok[qi]) continue;
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int d = 0; d < DT; d++)    // O[q][d = 16d + 4fg + r], written in the next GEMM's operand layout
+            act_store4<bf16_t>((bf16_t*)p.out, tok0 + s_idx[qi], head[qi] * HD + d * 16 + fg * 4, p.out_stride, o[qi][d] * inv);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -808,6 +808,8 @@ void norm(nvl_model* m, float* x, const int32_t* rows_idx, const DevTensor& w, c
     NVL_HIP(hipGetLastError());
 }
 
+static int g_attn_tq2 = 1;     // nvl_set_tuning key 10: two query sub-tiles per wave in the prefill attention kernel
+                               // (0 = never, 1 = when the grid still fills the chip, 2 = always)
 void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, double flops, bool fused_qkv = false) {
     AttnArgs a{};
     a.q = m->q; a.q_stride = m->nH * m->hd;
@@ -833,10 +835,14 @@ void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, do
             else hipLaunchKernelGGL((attn_decode_bf16_kernel<128, 8, false>), grid, dim3(512), 0, m->stream, a);
         }
     } else {
-        const int qtiles = cdiv((int64_t)max_len * m->group, 64);
-        dim3 grid(qtiles, m->nKV, n_seqs);
-        if (m->hd == 64) hipLaunchKernelGGL((attn_bf16_kernel<64>), grid, dim3(256), 0, m->stream, a);
-        else hipLaunchKernelGGL((attn_bf16_kernel<128>), grid, dim3(256), 0, m->stream, a);
+        // hd 64: two 16-row query sub-tiles per wave (128 rows per workgroup) once there are enough rows to fill the chip;
+        // short prompts and hd 128 (register budget) keep one
+        const int64_t qrows = (int64_t)max_len * m->group;
+        const bool tq2 = m->hd == 64 && (g_attn_tq2 == 2 || (g_attn_tq2 == 1 && cdiv(qrows, 128) * m->nKV * n_seqs >= 512));
+        dim3 grid(cdiv(qrows, tq2 ? 128 : 64), m->nKV, n_seqs);
+        if (tq2) hipLaunchKernelGGL((attn_bf16_kernel<64, 2>), grid, dim3(256), 0, m->stream, a);
+        else if (m->hd == 64) hipLaunchKernelGGL((attn_bf16_kernel<64, 1>), grid, dim3(256), 0, m->stream, a);
+        else hipLaunchKernelGGL((attn_bf16_kernel<128, 1>), grid, dim3(256), 0, m->stream, a);
     }
     NVL_HIP(hipGetLastError());
 }

@@ -120,6 +120,23 @@ def test_attention(gpu, oracle, nH, nKV, S, T, precision):
     assert rel_err(got, want) <= (5e-5 if precision == "f32" else BF16_TOL)
 
 
+@pytest.mark.parametrize("nH,nKV,S,T", [(4, 2, 5, 5), (2, 2, 33, 100), (3, 1, 7, 64), (71, 1, 2, 130), (8, 2, 130, 130),
+                                        (4, 2, 300, 1400), (8, 2, 257, 257)])
+def test_attention_two_query_subtiles_per_wave(gpu, oracle, nH, nKV, S, T):
+    """attn_bf16_kernel<64, 2> (128 query rows per workgroup: the form large prefill batches take), forced on small
+    shapes: ragged row counts, rows past the end of a sub-tile, diagonal and fully visible key tiles."""
+    r = rng(nH * 10 + T)
+    q = r.standard_normal((nH, S, 64), dtype=np.float32)
+    k = r.standard_normal((nKV, T, 64), dtype=np.float32)
+    v = r.standard_normal((nKV, T, 64), dtype=np.float32)
+    old = gpu.lib().nvl_set_tuning(10, 2)
+    try:
+        got = gpu.ops.attention(q, k, v, precision="bf16")
+    finally:
+        gpu.lib().nvl_set_tuning(10, old)
+    assert rel_err(got, oracle.gqa_core(q, k, v)) <= BF16_TOL
+
+
 @pytest.mark.parametrize("nH,nKV,S,T,hd", [(8, 2, 1, 2100, 64),      # decode: > 1024 keys -> the split-T loop runs twice per wave
                                             (4, 4, 1, 1100, 64), (4, 1, 1, 1500, 128),
                                             (4, 2, 300, 1400, 64)])  # chunked prefill against a long cache
