@@ -838,6 +838,9 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
     }
 }
 
+static int g_chunk_max_m = 192;    // largest M run as 64-row passes of the decode form (nvl_set_tuning key 11; 64 = off)
+constexpr int CHUNK_FEW_MAX_M = 256;   // measured on Llama-3.2-1B decode: passes win at 256 rows, tiles at 384 (profiles/r01g_large_decode_batches.txt)
+static int g_chunk_min_tiles = 160; // ... and up to CHUNK_FEW_MAX_M rows when the tile grid would be smaller than this (key 12)
 static int g_msplit_ks = 8;         // K split of the deferred-norm residual projections (nvl_set_tuning key 6)
 static int g_narrow_waves = 1024;   // waves per narrow-form launch (nvl_set_tuning key 5); in the model (weights cold from HBM) fewer,
                                     // longer per-wave streams win: B=8 +8 %, B=16 +8 %, B=32 +3 % decode vs 4096
@@ -957,6 +960,25 @@ template <int EPI, typename OutT>
 static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
     if (a.tile_map) { launch_gemm_grouped<EPI, OutT>(st, a, a.M); return; }   // a.M carries the m-tile bound
     if (launch_gemm_skinny_bf16<EPI, OutT>(st, a)) return;
+    if constexpr (EPI != EPI_QKV) {
+        // 64 < M <= g_chunk_max_m (large decode batches): the tile kernels would launch only N/128 workgroups, far too
+        // few to stream the weights at HBM rate.  Run the decode form once per 64 activation rows instead: the
+        // weights are read ceil(M/64) times, the later passes mostly from the Infinity Cache.
+        // Up to 256 rows the passes still win for the narrow projections (QKV, O, FFN-down), whose 128x128 tiles would
+        // fill well under a chip's worth of workgroups.
+        const bool few_tiles = a.M <= CHUNK_FEW_MAX_M && g_chunk_max_m > 64 && cdiv(a.M, 128) * cdiv(a.N, 128) < g_chunk_min_tiles;
+        if (a.M > 64 && (a.M <= g_chunk_max_m || few_tiles) && !a.a_rows && !a.seg && !a.sk_part && !a.rs_out && !a.rs_in && a.K % 32 == 0 &&
+            g_force_tile == 0) {
+            for (int r0 = 0; r0 < a.M; r0 += 64) {
+                GemmArgs c = a;
+                c.A = (const bf16_t*)a.A + (int64_t)r0 * a.lda;      // fragment-major: 16-row tiles are contiguous
+                c.M = a.M - r0 < 64 ? a.M - r0 : 64;
+                c.c_row0 = a.c_row0 + r0;
+                if (!launch_gemm_skinny_bf16<EPI, OutT>(st, c)) break;
+                if (r0 + 64 >= a.M) return;
+            }
+        }
+    }
     if constexpr (EPI == EPI_QKV) {
         if (a.qkv.hd == 128) {     // a wave must own a whole 128-column head: 256x256 tile as 4x2 waves of 64x128
             const int t3 = cdiv(a.M, 256) * cdiv(a.N, 256);

@@ -1,0 +1,8 @@
+# decode throughput of large batches: bench.py at B x 128 prompt x 128 steps, tuning overrides in $2
+rm -f gpurun_out/b_chunk_sweep.log
+for cfg in "192 11=192" "256 11=192" "256 11=64" "384 11=192" "384 11=64" "512 11=192" "512 11=64"; do set -- $cfg; echo "B=$1 $2" >> gpurun_out/b_chunk_sweep.log; timeout -k 10 200 python bench.py --no-cpu-baseline --prompt 128 --gen 128 --batch $1 --steps 2 --tune $2 2>&1 | python3 -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print(d['value'], d['prefill_tokens_per_s'], d['decode_tokens_per_s'])
+" >> gpurun_out/b_chunk_sweep.log || exit 1; done

@@ -227,3 +227,36 @@ def test_decode_greedy_equals_stepwise(gpu, oracle, family, precision):
         hm.decode_greedy(ids, got[-1], cfg["max_seq_len"])
     assert [hm.seq_len(i) for i in ids] == [p + steps + 1 for p in pos]
     hm.close()
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+@pytest.mark.parametrize("nseq", [80, 128, 200])
+def test_large_decode_batch_matches_oracle(gpu, oracle, family, nseq):
+    """Decode batches of 64 < M <= 256 rows run the decode GEMM form in 64-row passes (80 = 64 + a ragged 16; above 192
+    rows only the projections with small tile grids) with the fused decode attention: the logits of every sequence
+    match the oracle, and so does the 128x128 tile path (tuning key 11 = 64)."""
+    cfg = gpu.synth.tiny_config(family)
+    w = gpu.synth.make_weights(cfg, seed=7, scale=0.05)
+    om = oracle.OracleModel(cfg, w)
+    hm = gpu.HipTransformerModel(cfg, w, precision="bf16", max_seqs=nseq, max_batch_tokens=1024)
+    r = np.random.default_rng(5)
+    ids = list(range(nseq))
+    prompts = [r.integers(0, cfg["vocab_size"], int(r.integers(1, 5))).tolist() for _ in ids]
+    forced = r.integers(0, cfg["vocab_size"], nseq).tolist()
+    want = []
+    for p, t in zip(prompts, forced):
+        kv = om.new_cache()
+        om.forward_with_cache(p, kv, 0)
+        want.append(om.forward_with_cache([t], kv, len(p))[-1])
+    want = np.stack(want)
+    for chunk_max in (192, 64):
+        old = gpu.lib().nvl_set_tuning(11, chunk_max)
+        try:
+            for i in ids:
+                hm.seq_reset(i)
+            hm.forward_batch(ids, prompts, [0] * nseq, want_logits=False)
+            got, _ = hm.forward_batch(ids, [[t] for t in forced], [len(p) for p in prompts])
+        finally:
+            gpu.lib().nvl_set_tuning(11, old)
+        assert rel_err(got, want) <= TOL["bf16"], f"key 11 = {chunk_max}"
+    hm.close()
