@@ -353,9 +353,10 @@ int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int 
  * key 3: deferred RMSNorm in decode (0 off, 1 on, 2 on without the activation-tile split, 3 only the O-proj -> FFN-up seam).
  * keys 4-6 (sweeps): K split of the wide form, waves per narrow-form launch, K split of the deferred-norm residual
  * projections.  key 7: decode seam kernel, 8: MoE small-batch fusion, 9: 16-row norm kernel, 10: prefill attention
- * with 128 query rows per workgroup (0 never, 1 automatic, 2 always).  key 11: largest M run as 64-row passes of
- * the decode GEMM form (default 192; 64 = off); key 12: up to 256 rows the
- * passes are also used when the 128x128 tile grid would have fewer workgroups than this (default 160).  Returns the previous value. */
+ * with 128 query rows per workgroup (0 never, 1 automatic, 2 always).  keys 11-14: decode batches of 65..512 rows (key 11, default 512; 64 = off) run the
+ * projections whose 128x128 tile grid has fewer than key 12 (160) workgroups as ceil(M/64) groups of 64 rows of the
+ * decode GEMM form, in one launch interleaved over the weight blocks (key 13 = 1) or one launch per group (0); up to
+ * key 14 rows (64) every projection does.  Returns the previous value. */
 int nvl_set_tuning(int key, int value);
 
 #ifdef __cplusplus

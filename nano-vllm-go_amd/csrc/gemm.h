@@ -84,6 +84,9 @@ struct GemmArgs {
     // between the two projections disappears; all sums keep a fixed order.
     int m_split;            // narrow decode kernel: gridDim.y indexes 16-row activation tiles (not K slices): the
                             // workgroups of a weight tile stream the same weights (one XCD: L2 serves the second)
+    int m_passes;           // decode kernels, 64 < M: the launch covers m_passes = ceil(M/64) groups of 64 activation rows;
+                            // the workgroups of one weight tile sit 8 block ids apart — same XCD, dispatched together —
+                            // so the weights cross HBM once and the later groups hit L2 (see launch_gemm_bf16)
     const float* nrm_w;     // producer: weight of the norm that follows, [N]
     bf16_t* nrm_xn;         // producer: xn_raw [M_pad16][N] fragment-major
     float* rs_out;          // producer: [64 rows][N/16]
@@ -546,6 +549,16 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmArgs p) {
 //     fused epilogue (bias / residual / SwiGLU / GELU) runs once per output element.  For SwiGLU
 //     NTW = 2: tile 0 is the gate block, tile 1 the up block of the same 16 features.
 // ------------------------------------------------------------------------------------------
+// m_passes > 1: block id -> (weight block, 64-row activation group).  Ids that differ by 8 share an XCD and are
+// dispatched back to back: the groups of one weight block stream the same weights at the same time.
+__device__ __forceinline__ void skinny_pass_remap(GemmArgs& p, int& bx) {
+    const int slot = bx >> 3, z = slot % p.m_passes;
+    bx = (slot / p.m_passes) * 8 + (bx & 7);
+    p.A = (const bf16_t*)p.A + (int64_t)z * 64 * p.K;      // fragment-major: 16-row tiles are contiguous
+    p.c_row0 += z * 64;
+    p.M = min(64, p.M - z * 64);                           // the last group may be ragged (operands are padded to 64 rows)
+}
+
 template <int MT, int NTW, int U, int EPI, typename OutT>
 __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -554,7 +567,9 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     const int ksplit = (blockDim.x >> 6) / NTW;
     const int tile = wave / ksplit, kw = wave - tile * ksplit;
     const int fr = lane & 15, fg = lane >> 4;
-    const int nt0 = blockIdx.x * NTW;                // first 16-row weight tile of this workgroup
+    int bx = blockIdx.x;
+    if (p.m_passes > 1) skinny_pass_remap(p, bx);
+    const int nt0 = bx * NTW;                        // first 16-row weight tile of this workgroup
     // K/32 k-steps dealt over (gridDim.y slices) x (ksplit waves) as evenly as possible (K need not divide:
     // Falcon's 4544 = 142 steps)
     const int i_off = p.m_split ? blockIdx.y : 0;                  // first 16-row activation tile of this workgroup
@@ -752,7 +767,9 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
     const int tid = threadIdx.x, lane = tid & 63, kw = tid >> 6;
     const int ksplit = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int nt0 = blockIdx.x * NTB;
+    int bx = blockIdx.x;
+    if (p.m_passes > 1) skinny_pass_remap(p, bx);
+    const int nt0 = bx * NTB;
     const int nks = p.K >> 5, q = nks / ksplit, rr = nks - q * ksplit;
     const int my_steps = q + (kw < rr ? 1 : 0);
     const int ks0 = kw * q + (kw < rr ? kw : rr);
@@ -838,9 +855,12 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
     }
 }
 
-static int g_chunk_max_m = 192;    // largest M run as 64-row passes of the decode form (nvl_set_tuning key 11; 64 = off)
-constexpr int CHUNK_FEW_MAX_M = 256;   // measured on Llama-3.2-1B decode: passes win at 256 rows, tiles at 384 (profiles/r01g_large_decode_batches.txt)
-static int g_chunk_min_tiles = 160; // ... and up to CHUNK_FEW_MAX_M rows when the tile grid would be smaller than this (key 12)
+static int g_chunk_max_m = 512;    // largest M that uses 64-row passes of the decode form at all (nvl_set_tuning key 11; 64 = off)
+static int g_chunk_all_m = 64;     // up to here every projection does; above, only those whose 128x128 tile grid would
+                                   // have fewer than g_chunk_min_tiles workgroups (keys 14, 12).  Measured: the mix wins
+                                   // from 96 rows on (profiles/r01g_large_decode_batches.txt)
+static int g_pass_interleave = 1;   // 64-row groups of one projection in ONE launch (key 13; 0 = one launch per group)
+static int g_chunk_min_tiles = 160;
 static int g_msplit_ks = 8;         // K split of the deferred-norm residual projections (nvl_set_tuning key 6)
 static int g_narrow_waves = 1024;   // waves per narrow-form launch (nvl_set_tuning key 5); in the model (weights cold from HBM) fewer,
                                     // longer per-wave streams win: B=8 +8 %, B=16 +8 %, B=32 +3 % decode vs 4096
@@ -848,10 +868,27 @@ static int g_wide_ksplit = 0;   // experiment (nvl_set_tuning key 4): K split of
 static int g_force_ntw = 0, g_force_ksplit = 0;   // tuning overrides (nvl_bench_gemm only)
 static int g_force_tile = 0;                      // 0 automatic, 1: 128x128x2st, 2: 256x128x3st, 3: 256x256x2st, 5: ping-pong 256x256
 
+template <int EPI, typename OutT>
+static inline bool launch_gemm_skinny_bf16(hipStream_t st, const GemmArgs& a);
+static inline int skinny_rows(const GemmArgs& a) { return a.m_passes > 1 && a.M > 64 ? 64 : a.M; }   // rows a workgroup covers
+// the groups of 64 rows as separate launches (weight-block count not a multiple of 8, or key 13 = 0)
+template <int EPI, typename OutT>
+static inline bool launch_skinny_passes_serial(hipStream_t st, const GemmArgs& a) {
+    for (int r0 = 0; r0 < a.M; r0 += 64) {
+        GemmArgs c = a;
+        c.m_passes = 0;
+        c.A = (const bf16_t*)a.A + (int64_t)r0 * a.K;
+        c.M = a.M - r0 < 64 ? a.M - r0 : 64;
+        c.c_row0 = a.c_row0 + r0;
+        if (!launch_gemm_skinny_bf16<EPI, OutT>(st, c)) return false;
+    }
+    return true;
+}
+
 // skinny dispatch: M <= 64, no gather/segments.  Returns false when the shape is not eligible.
 template <int NTW, int EPI, typename OutT>
 static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
-    const int MT = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+    const int MT = skinny_rows(a) <= 16 ? 1 : (skinny_rows(a) <= 32 ? 2 : 4);
     const int U = MT <= 2 ? 4 : 2;                       // register budget: (1+MT)*U*2 fragments
     const int nblocks = cdiv(cdiv(a.N, 16), NTW);        // weight rows are padded to 128: all tiles exist
     const int KS = (EPI == EPI_RESID && a.sk_part && a.sk_slices > 1) ? a.sk_slices : 1;
@@ -872,7 +909,8 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
     while (ksplit > 1 && ((a.K >> 5) / (ksplit * KS) < U || ksplit * NTW > 16)) ksplit >>= 1;   // >= one block of U k-steps per wave
     if (a.K % 32 != 0) return false;
     const size_t lds = (size_t)NTW * ksplit * MT * 64 * 16;
-    dim3 grid(nblocks, KS), block(NTW * ksplit * 64);
+    if (a.m_passes > 1 && (nblocks % 8 != 0 || KS != 1)) return launch_skinny_passes_serial<EPI, OutT>(st, a);
+    dim3 grid(nblocks * (a.m_passes > 1 ? a.m_passes : 1), KS), block(NTW * ksplit * 64);
 #define NVL_SK(MTv, Uv) hipLaunchKernelGGL((gemm_skinny_bf16_kernel<MTv, NTW, Uv, EPI, OutT>), grid, block, lds, st, a)
     if (MT == 1) NVL_SK(1, 4); else if (MT == 2) NVL_SK(2, 4); else NVL_SK(4, 2);
 #undef NVL_SK
@@ -883,7 +921,7 @@ static inline bool launch_gemm_skinny_wide(hipStream_t st, const GemmArgs& a) {
     constexpr int NTB = 4;
     if (a.K % 32 != 0 || a.sk_part) return false;
     const int groups = cdiv(cdiv(a.N, 16), NTB);     // weight rows are padded to 256: every tile of a group exists
-    const int MT = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+    const int MT = skinny_rows(a) <= 16 ? 1 : (skinny_rows(a) <= 32 ? 2 : 4);
     const int U = MT <= 2 ? 4 : 2;
     // ~512 waves per launch (256-VGPR waves, each with up to 32 KiB of weights in flight) stream best from HBM: longer
     // per-wave K slices beat more waves (in the model, weights cold: FFN-up ksplit 2 > 4 > 8 > 1; LM head, 8B FFN-up 2)
@@ -893,6 +931,8 @@ static inline bool launch_gemm_skinny_wide(hipStream_t st, const GemmArgs& a) {
     else { while (ksplit > 2 && groups * ksplit > 512) ksplit >>= 1; if (groups >= 1024) ksplit = 1; }   // LM head: one wave per group (cold sweep: 96 vs 104 us)
     while (ksplit > 1 && (a.K >> 5) / ksplit < U) ksplit >>= 1;
     const size_t lds = (size_t)ksplit * NTB * MT * 64 * 16;
+    if (a.m_passes > 1 && groups % 8 != 0) return launch_skinny_passes_serial<EPI, OutT>(st, a);
+    const int wgs = groups * (a.m_passes > 1 ? a.m_passes : 1);
 #define NVL_SKW(MTv, Uv)                                                                                               \
     do {                                                                                                               \
         static bool attr = false;                                                                                      \
@@ -901,7 +941,7 @@ static inline bool launch_gemm_skinny_wide(hipStream_t st, const GemmArgs& a) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 8 * NTB * MTv * 64 * 16);            \
             attr = true;                                                                                               \
         }                                                                                                              \
-        hipLaunchKernelGGL((gemm_skinny_wide_bf16_kernel<MTv, NTB, Uv, EPI, OutT>), dim3(groups), dim3(ksplit * 64),   \
+        hipLaunchKernelGGL((gemm_skinny_wide_bf16_kernel<MTv, NTB, Uv, EPI, OutT>), dim3(wgs), dim3(ksplit * 64),      \
                            lds, st, a);                                                                                \
     } while (0)
     if (MT == 1) NVL_SKW(1, 4); else if (MT == 2) NVL_SKW(2, 4); else NVL_SKW(4, 2);
@@ -911,10 +951,10 @@ static inline bool launch_gemm_skinny_wide(hipStream_t st, const GemmArgs& a) {
 template <int EPI, typename OutT>
 static inline bool launch_gemm_skinny_bf16(hipStream_t st, const GemmArgs& a) {
     if (EPI == EPI_QKV) return false;               // prefill-only epilogue (a decode workgroup owns 16 columns, not a head)
-    if (a.M > 64 || a.a_rows || a.seg || a.tile_map) return false;
+    if (skinny_rows(a) > 64 || a.a_rows || a.seg || a.tile_map) return false;
     if constexpr (EPI == EPI_SWIGLU || EPI == EPI_STORE || EPI == EPI_GELU) {
         // wide-N form once its 64-row groups fill the chip (g_force_ntw: 8 forces it, 1/2/4 force the narrow form)
-        const bool wide_ok = a.M > 16 && cdiv(a.N, 64) >= 256 && !a.sk_part;   // M <= 16: the narrow form streams as fast
+        const bool wide_ok = skinny_rows(a) > 16 && cdiv(a.N, 64) >= 256 && !a.sk_part;   // M <= 16: the narrow form streams as fast
         if (g_force_ntw == 8 || (g_force_ntw == 0 && wide_ok)) { if (launch_gemm_skinny_wide<EPI, OutT>(st, a)) return true; }
     }
     if (EPI == EPI_SWIGLU) return launch_gemm_skinny_ntw<2, EPI, OutT>(st, a);
@@ -961,22 +1001,19 @@ static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
     if (a.tile_map) { launch_gemm_grouped<EPI, OutT>(st, a, a.M); return; }   // a.M carries the m-tile bound
     if (launch_gemm_skinny_bf16<EPI, OutT>(st, a)) return;
     if constexpr (EPI != EPI_QKV) {
-        // 64 < M <= g_chunk_max_m (large decode batches): the tile kernels would launch only N/128 workgroups, far too
-        // few to stream the weights at HBM rate.  Run the decode form once per 64 activation rows instead: the
-        // weights are read ceil(M/64) times, the later passes mostly from the Infinity Cache.
-        // Up to 256 rows the passes still win for the narrow projections (QKV, O, FFN-down), whose 128x128 tiles would
-        // fill well under a chip's worth of workgroups.
-        const bool few_tiles = a.M <= CHUNK_FEW_MAX_M && g_chunk_max_m > 64 && cdiv(a.M, 128) * cdiv(a.N, 128) < g_chunk_min_tiles;
-        if (a.M > 64 && (a.M <= g_chunk_max_m || few_tiles) && !a.a_rows && !a.seg && !a.sk_part && !a.rs_out && !a.rs_in && a.K % 32 == 0 &&
+        // 64 < M <= g_chunk_max_m (large decode batches): the tile kernels would launch only N/128 * M/128 workgroups, far
+        // too few to stream the weights at HBM rate.  Run the decode form over ceil(M/64) groups of 64 activation rows
+        // in one launch instead (GemmArgs::m_passes): the groups of a weight block run side by side on one XCD, so the
+        // weights cross HBM once.  Only the narrow projections (QKV, O, FFN-down) do; FFN-up and the LM head have enough
+        // tiles (g_chunk_all_m: below it every projection would).
+        const bool few_tiles = cdiv(a.M, 128) * cdiv(a.N, 128) < g_chunk_min_tiles;
+        if (a.M > 64 && a.M <= g_chunk_max_m && (a.M <= g_chunk_all_m || few_tiles) && !a.a_rows && !a.seg && !a.sk_part && !a.rs_out && !a.rs_in && a.K % 32 == 0 &&
             g_force_tile == 0) {
-            for (int r0 = 0; r0 < a.M; r0 += 64) {
-                GemmArgs c = a;
-                c.A = (const bf16_t*)a.A + (int64_t)r0 * a.lda;      // fragment-major: 16-row tiles are contiguous
-                c.M = a.M - r0 < 64 ? a.M - r0 : 64;
-                c.c_row0 = a.c_row0 + r0;
-                if (!launch_gemm_skinny_bf16<EPI, OutT>(st, c)) break;
-                if (r0 + 64 >= a.M) return;
-            }
+            GemmArgs c = a;
+            c.m_passes = cdiv(a.M, 64);
+            const bool ok = g_pass_interleave ? launch_gemm_skinny_bf16<EPI, OutT>(st, c)
+                                              : launch_skinny_passes_serial<EPI, OutT>(st, c);
+            if (ok) return;
         }
     }
     if constexpr (EPI == EPI_QKV) {

@@ -1108,9 +1108,9 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
             norm(m, m->x, nullptr, l.t[NVL_T_ATTN_NORM_W], l.t[NVL_T_ATTN_NORM_B], m->xn, M);
         xn_deferred = false;
         bool fused_dec = false;
-        // a decode batch of 64 < M <= 256 rows keeps the decode form (64-row passes, gemm.h) and the fused
+        // a decode batch of 64 < M <= g_chunk_max_m rows keeps the decode form (64-row passes, gemm.h) and the fused
         // decode attention
-        const bool big_decode = max_len == 1 && M <= CHUNK_FEW_MAX_M && g_chunk_max_m > 64 && m->group <= 16 && g_force_tile == 0;
+        const bool big_decode = max_len == 1 && M <= g_chunk_max_m && m->group <= 16 && g_force_tile == 0;
         if (!m->f32 && M > 64 && !big_decode) {
             // prefill: RoPE + Q/K/V placement fused into the projection's epilogue (no fp32 qkv round trip)
             GemmArgs a = mk(m->xn, H, l.w_qkv, nullptr, 0, l.b_qkv, 1.f, M, m->n_qkv, H);

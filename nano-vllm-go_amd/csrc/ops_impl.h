@@ -395,6 +395,8 @@ extern "C" int nvl_bench_gemm(int device, int M, int N, int K, int epi, int forc
 extern "C" int nvl_set_tuning(int key, int value) {
     if (key == 0) { const int old = g_force_tile; g_force_tile = value; return old; }
     if (key == 1) { const int old = g_sk_slices; g_sk_slices = value; return old; }
+    if (key == 14) { const int old = g_chunk_all_m; g_chunk_all_m = value; return old; }
+    if (key == 13) { const int old = g_pass_interleave; g_pass_interleave = value; return old; }
     if (key == 12) { const int old = g_chunk_min_tiles; g_chunk_min_tiles = value; return old; }
     if (key == 11) { const int old = g_chunk_max_m; g_chunk_max_m = value; return old; }
     if (key == 10) { const int old = g_attn_tq2; g_attn_tq2 = value; return old; }

@@ -232,9 +232,10 @@ def test_decode_greedy_equals_stepwise(gpu, oracle, family, precision):
 @pytest.mark.parametrize("family", FAMILIES)
 @pytest.mark.parametrize("nseq", [80, 128, 200])
 def test_large_decode_batch_matches_oracle(gpu, oracle, family, nseq):
-    """Decode batches of 64 < M <= 256 rows run the decode GEMM form in 64-row passes (80 = 64 + a ragged 16; above 192
-    rows only the projections with small tile grids) with the fused decode attention: the logits of every sequence
-    match the oracle, and so does the 128x128 tile path (tuning key 11 = 64)."""
+    """Decode batches of 64 < M <= 512 rows run the narrow projections as groups of 64 activation rows of the decode
+    GEMM form (80 = 64 + a ragged 16) and keep the fused decode attention: the logits of every sequence match the
+    oracle — with the groups interleaved in one launch (the default), launched one by one (key 13 = 0), and on the
+    128x128 tile path (key 11 = 64)."""
     cfg = gpu.synth.tiny_config(family)
     w = gpu.synth.make_weights(cfg, seed=7, scale=0.05)
     om = oracle.OracleModel(cfg, w)
@@ -249,8 +250,9 @@ def test_large_decode_batch_matches_oracle(gpu, oracle, family, nseq):
         om.forward_with_cache(p, kv, 0)
         want.append(om.forward_with_cache([t], kv, len(p))[-1])
     want = np.stack(want)
-    for chunk_max in (192, 64):
+    for chunk_max, interleave in ((512, 1), (512, 0), (64, 1)):
         old = gpu.lib().nvl_set_tuning(11, chunk_max)
+        old13 = gpu.lib().nvl_set_tuning(13, interleave)
         try:
             for i in ids:
                 hm.seq_reset(i)
@@ -258,5 +260,6 @@ def test_large_decode_batch_matches_oracle(gpu, oracle, family, nseq):
             got, _ = hm.forward_batch(ids, [[t] for t in forced], [len(p) for p in prompts])
         finally:
             gpu.lib().nvl_set_tuning(11, old)
-        assert rel_err(got, want) <= TOL["bf16"], f"key 11 = {chunk_max}"
+            gpu.lib().nvl_set_tuning(13, old13)
+        assert rel_err(got, want) <= TOL["bf16"], f"key 11 = {chunk_max}, key 13 = {interleave}"
     hm.close()

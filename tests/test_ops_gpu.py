@@ -55,6 +55,28 @@ def test_matmul_prefill_tile_kernels(gpu, oracle, tile, m, k, n):
         gpu.lib().nvl_set_tuning(0, old)
 
 
+@pytest.mark.parametrize("interleave", [1, 0])
+@pytest.mark.parametrize("m,k,n", [(65, 256, 128), (130, 2048, 2048), (200, 512, 3072), (512, 192, 1003), (96, 128, 200)])
+def test_matmul_row_groups_of_decode_form(gpu, oracle, interleave, m, k, n):
+    """64 < M <= 512 with a small tile grid: ceil(M/64) groups of 64 activation rows of the decode kernels — one
+    interleaved launch when the weight-block count is a multiple of 8 (n = 128, 2048, 3072), one launch per group
+    otherwise (n = 1003, 200) or under key 13 = 0; ragged last groups of 1, 2, 8 and 32 rows.  The integer case
+    is exact and asymmetric, so a group landing on the wrong output rows cannot pass."""
+    r = rng(m + n)
+    a = r.standard_normal((m, k), dtype=np.float32)
+    b = r.standard_normal((k, n), dtype=np.float32) * 0.05
+    ai = (np.arange(m * k).reshape(m, k) % 7).astype(np.float32)
+    bi = (np.arange(k * n).reshape(k, n) % 5).astype(np.float32) - 2.0        # |sums| < 2^24: exact in fp32
+    old = gpu.lib().nvl_set_tuning(13, interleave)
+    try:
+        got = gpu.ops.mat_mul(a, b, precision="bf16")
+        goti = gpu.ops.mat_mul(ai, bi, precision="bf16")
+    finally:
+        gpu.lib().nvl_set_tuning(13, old)
+    assert rel_err(got, oracle.matmul(a, b)) <= BF16_TOL
+    assert np.array_equal(goti, oracle.matmul(ai, bi))
+
+
 def test_matmul_bf16_exact_on_integers(gpu, oracle):
     """A=I-style check with ASYMMETRIC B (catches a transposed C write): small integers are exact in bf16."""
     k, n = 128, 192
