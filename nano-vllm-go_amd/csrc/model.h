@@ -108,6 +108,7 @@ struct nvl_model {
     int32_t *moe_counts = nullptr, *moe_cursor = nullptr, *moe_tile_map = nullptr, *moe_n_mtiles = nullptr;
     // decode split-K: partial slices of the last residual GEMM, consumed by the next norm launch
     float* rs_part = nullptr;    // deferred RMSNorm: [H/16][64] partial sums of x^2 (gemm.h)
+    int ctx_hint = 0;    // longest context (keys) of the batch being enqueued; 0 = unknown (decode attention sizing)
     float* sk_part = nullptr; int sk_max_slices = 4; int pending_slices = 0, pending_rows = 0; float pending_alpha = 1.f; const float* pending_part = nullptr;
     const int32_t* pending_slot_of = nullptr; const float* pending_gate_w = nullptr;   // MoE combine folded into the next norm
     // per-call metadata (one pinned host block mirrored on the device)

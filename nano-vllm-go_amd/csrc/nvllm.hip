@@ -808,6 +808,7 @@ void norm(nvl_model* m, float* x, const int32_t* rows_idx, const DevTensor& w, c
     NVL_HIP(hipGetLastError());
 }
 
+static int g_attn_nw = 0;      // nvl_set_tuning key 15: waves per decode-attention workgroup (0 = from the context length, 2, 4, 8)
 static int g_attn_tq2 = 1;     // nvl_set_tuning key 10: two query sub-tiles per wave in the prefill attention kernel
                                // (0 = never, 1 = when the grid still fills the chip, 2 = always)
 void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, double flops, bool fused_qkv = false) {
@@ -826,14 +827,28 @@ void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, do
         hipLaunchKernelGGL(attn_f32_kernel, dim3(max_len, m->nH, n_seqs), dim3(256), lds, m->stream, a, m->hd);
     } else if (max_len == 1 && m->group <= 16) {
         dim3 grid(m->nKV, n_seqs);
+        // waves per workgroup: each wave takes NT2 key tiles per round trip (2 for hd 64, 1 for hd 128).  Short contexts
+        // need fewer than 8 waves (idle waves still cost LDS and a slot in the final merge), and once the grid alone
+        // fills the chip (>= 2 workgroups per CU) fewer, longer-running waves stream better than many short ones
+        // (profiles/r01g_decode_attention_waves.txt).  ctx_hint = the batch's longest context when the caller knows it.
+        const int n_kt = m->ctx_hint > 0 ? (m->ctx_hint - 1) / 64 + 1 : 1 << 20;
+        const int per_wave = m->hd == 64 ? 2 : 1;
+        const int wgs = m->nKV * n_seqs;
+        const int cap = wgs >= 512 ? 2 : (wgs >= 320 ? 4 : 8);
+        int nw = n_kt <= 2 * per_wave ? 2 : (n_kt <= 4 * per_wave ? 4 : 8);
+        nw = g_attn_nw ? g_attn_nw : std::min(nw, cap);
         if (fused_qkv) {   // RoPE + KV append + attention in one launch, straight from the QKV projection's fp32 output
             a.qkv = m->qkv; a.qkv_stride = m->n_qkv; a.cos_t = m->rope_cos; a.sin_t = m->rope_sin;
-            if (m->hd == 64) hipLaunchKernelGGL((attn_decode_bf16_kernel<64, 8, true>), grid, dim3(512), 0, m->stream, a);
-            else hipLaunchKernelGGL((attn_decode_bf16_kernel<128, 8, true>), grid, dim3(512), 0, m->stream, a);
-        } else {
-            if (m->hd == 64) hipLaunchKernelGGL((attn_decode_bf16_kernel<64, 8, false>), grid, dim3(512), 0, m->stream, a);
-            else hipLaunchKernelGGL((attn_decode_bf16_kernel<128, 8, false>), grid, dim3(512), 0, m->stream, a);
         }
+#define NVL_DEC(HDv, FUSEDv)                                                                                           \
+        do {                                                                                                           \
+            if (nw == 2) hipLaunchKernelGGL((attn_decode_bf16_kernel<HDv, 2, FUSEDv>), grid, dim3(128), 0, m->stream, a);      \
+            else if (nw == 4) hipLaunchKernelGGL((attn_decode_bf16_kernel<HDv, 4, FUSEDv>), grid, dim3(256), 0, m->stream, a); \
+            else hipLaunchKernelGGL((attn_decode_bf16_kernel<HDv, 8, FUSEDv>), grid, dim3(512), 0, m->stream, a);              \
+        } while (0)
+        if (fused_qkv) { if (m->hd == 64) NVL_DEC(64, true); else NVL_DEC(128, true); }
+        else { if (m->hd == 64) NVL_DEC(64, false); else NVL_DEC(128, false); }
+#undef NVL_DEC
     } else {
         // hd 64: two 16-row query sub-tiles per wave (128 rows per workgroup) once there are enough rows to fill the chip;
         // short prompts and hd 128 (register budget) keep one
@@ -1197,6 +1212,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
         NVL_HIP(hipGetLastError());
     }
     m->last_rows = rows;
+    m->ctx_hint = 0;
     return rows;
 }
 
@@ -1267,6 +1283,7 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
     for (int i = 0; i < n_seqs; i++) {
         const double s = seq_lens[i], p0 = pos_offsets[i];
         attn_flops += 4.0 * m->hd * m->nH * (s * p0 + s * (s + 1) / 2);
+        m->ctx_hint = std::max(m->ctx_hint, (int)(pos_offsets[i] + seq_lens[i]));
     }
     const bool all = (flags & NVL_FWD_ALL_LOGITS) != 0;
     const int rows = enqueue_forward(m, md, n_seqs, M, max_len, attn_flops, flags);
@@ -1345,6 +1362,7 @@ extern "C" int nvl_forward_paged(nvl_model* m, int n_seqs, const int32_t* tokens
     for (int i = 0; i < n_seqs; i++) {
         const double s = seq_lens[i], p0 = pos_offsets[i];
         attn_flops += 4.0 * m->hd * m->nH * (s * p0 + s * (s + 1) / 2);
+        m->ctx_hint = std::max(m->ctx_hint, (int)(pos_offsets[i] + seq_lens[i]));
     }
     const bool all = (flags & NVL_FWD_ALL_LOGITS) != 0;
     const int rows = enqueue_forward(m, md, n_seqs, M, max_len, attn_flops, flags);
@@ -1444,7 +1462,10 @@ void decode_loop(nvl_model* m, const Meta& hm, int n_seqs, int n_steps, int32_t*
     m->keep_hidden = false;                      // the per-layer taps belong to single nvl_forward calls
     for (int s = 0; s < n_steps; s++) {
         double attn_flops = 0;
-        for (int i = 0; i < n_seqs; i++) attn_flops += 4.0 * m->hd * m->nH * (double)(h_pos[i] + s + 1);
+        for (int i = 0; i < n_seqs; i++) {
+            attn_flops += 4.0 * m->hd * m->nH * (double)(h_pos[i] + s + 1);
+            m->ctx_hint = std::max(m->ctx_hint, h_pos[i] + s + 1);
+        }
         // bf16 path: the step's tail (argmax, token feedback) and the next step's head (embedding gather + layer 0's
         // norm) are one launch (decode_seam_kernel); fp32 parity mode keeps the separate kernels
         const bool seam_ok = (g_decode_seam || sp) && !m->f32 && m->H <= 1024 * NORM_ROW_MAXCH && m->H % 4 == 0;

@@ -395,6 +395,7 @@ extern "C" int nvl_bench_gemm(int device, int M, int N, int K, int epi, int forc
 extern "C" int nvl_set_tuning(int key, int value) {
     if (key == 0) { const int old = g_force_tile; g_force_tile = value; return old; }
     if (key == 1) { const int old = g_sk_slices; g_sk_slices = value; return old; }
+    if (key == 15) { const int old = g_attn_nw; g_attn_nw = value; return old; }
     if (key == 14) { const int old = g_chunk_all_m; g_chunk_all_m = value; return old; }
     if (key == 13) { const int old = g_pass_interleave; g_pass_interleave = value; return old; }
     if (key == 12) { const int old = g_chunk_min_tiles; g_chunk_min_tiles = value; return old; }

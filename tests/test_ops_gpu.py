@@ -173,6 +173,23 @@ def test_attention_long_context(gpu, oracle, nH, nKV, S, T, hd):
         assert rel_err(gpu.ops.attention(q, k, v, precision="f32"), want) <= 5e-5
 
 
+@pytest.mark.parametrize("nw", [2, 4, 8])
+@pytest.mark.parametrize("nKV,T,hd", [(2, 70, 64), (2, 2100, 64), (1, 700, 128), (4, 1, 64)])
+def test_decode_attention_wave_counts(gpu, oracle, nw, nKV, T, hd):
+    """The decode kernel's waves-per-workgroup variants (chosen from the batch's longest context; key 15 forces one)
+    give the same result for any context length: 2 waves walk 2100 keys in 9 rounds, 8 waves sit idle on 1 key."""
+    r = rng(T + nw)
+    q = r.standard_normal((4 * nKV, 1, hd), dtype=np.float32)
+    k = r.standard_normal((nKV, T, hd), dtype=np.float32)
+    v = r.standard_normal((nKV, T, hd), dtype=np.float32)
+    old = gpu.lib().nvl_set_tuning(15, nw)
+    try:
+        got = gpu.ops.attention(q, k, v, precision="bf16")
+    finally:
+        gpu.lib().nvl_set_tuning(15, old)
+    assert rel_err(got, oracle.gqa_core(q, k, v)) <= BF16_TOL
+
+
 def test_attention_custom_scale_and_hd128(gpu, oracle):
     r = rng(5)
     q = r.standard_normal((4, 6, 128), dtype=np.float32)
