@@ -24,6 +24,7 @@
 // f32 path (NVL_PRECISION_F32): plain LDS-tiled fp32 FMA kernel on row-major operands, k ascending —
 // the tight-tolerance parity mode, not a performance path.
 #pragma once
+#include <stdexcept>
 #include "common.h"
 
 namespace nvl {
@@ -557,6 +558,7 @@ __device__ __forceinline__ void skinny_pass_remap(GemmArgs& p, int& bx) {
     p.A = (const bf16_t*)p.A + (int64_t)z * 64 * p.K;      // fragment-major: 16-row tiles are contiguous
     p.c_row0 += z * 64;
     p.M = min(64, p.M - z * 64);                           // the last group may be ragged (operands are padded to 64 rows)
+    if (p.rs_in) p.rs_in += (int64_t)z * 64 * p.rs_tiles;  // deferred RMSNorm: this group's rows of the x^2 partials
 }
 
 template <int MT, int NTW, int U, int EPI, typename OutT>
@@ -870,6 +872,8 @@ static int g_force_tile = 0;                      // 0 automatic, 1: 128x128x2st
 
 template <int EPI, typename OutT>
 static inline bool launch_gemm_skinny_bf16(hipStream_t st, const GemmArgs& a);
+constexpr int DEFER_MAX_M = 64;     // deferred RMSNorm (decode): rows of the x^2 partial buffer.  128 was measured (B=128: the
+                                    // producer's one-workgroup-per-16-rows grid costs more than the 32 norm launches save: -13 %)
 static inline int skinny_rows(const GemmArgs& a) { return a.m_passes > 1 && a.M > 64 ? 64 : a.M; }   // rows a workgroup covers
 // the groups of 64 rows as separate launches (weight-block count not a multiple of 8, or key 13 = 0)
 template <int EPI, typename OutT>
@@ -880,6 +884,7 @@ static inline bool launch_skinny_passes_serial(hipStream_t st, const GemmArgs& a
         c.A = (const bf16_t*)a.A + (int64_t)r0 * a.K;
         c.M = a.M - r0 < 64 ? a.M - r0 : 64;
         c.c_row0 = a.c_row0 + r0;
+        if (a.rs_in) c.rs_in = a.rs_in + (int64_t)r0 * a.rs_tiles;
         if (!launch_gemm_skinny_bf16<EPI, OutT>(st, c)) return false;
     }
     return true;
@@ -951,7 +956,8 @@ static inline bool launch_gemm_skinny_wide(hipStream_t st, const GemmArgs& a) {
 template <int EPI, typename OutT>
 static inline bool launch_gemm_skinny_bf16(hipStream_t st, const GemmArgs& a) {
     if (EPI == EPI_QKV) return false;               // prefill-only epilogue (a decode workgroup owns 16 columns, not a head)
-    if (skinny_rows(a) > 64 || a.a_rows || a.seg || a.tile_map) return false;
+    const bool defer_producer = EPI == EPI_RESID && a.m_split && a.rs_out && a.M <= DEFER_MAX_M;   // one workgroup per 16-row tile
+    if ((skinny_rows(a) > 64 && !defer_producer) || a.a_rows || a.seg || a.tile_map) return false;
     if constexpr (EPI == EPI_SWIGLU || EPI == EPI_STORE || EPI == EPI_GELU) {
         // wide-N form once its 64-row groups fill the chip (g_force_ntw: 8 forces it, 1/2/4 force the narrow form)
         const bool wide_ok = skinny_rows(a) > 16 && cdiv(a.N, 64) >= 256 && !a.sk_part;   // M <= 16: the narrow form streams as fast
@@ -1007,7 +1013,7 @@ static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
         // weights cross HBM once.  Only the narrow projections (QKV, O, FFN-down) do; FFN-up and the LM head have enough
         // tiles (g_chunk_all_m: below it every projection would).
         const bool few_tiles = cdiv(a.M, 128) * cdiv(a.N, 128) < g_chunk_min_tiles;
-        if (a.M > 64 && a.M <= g_chunk_max_m && (a.M <= g_chunk_all_m || few_tiles) && !a.a_rows && !a.seg && !a.sk_part && !a.rs_out && !a.rs_in && a.K % 32 == 0 &&
+        if (a.M > 64 && a.M <= g_chunk_max_m && (a.M <= g_chunk_all_m || few_tiles || a.rs_in) && !a.a_rows && !a.seg && !a.sk_part && !a.rs_out && a.K % 32 == 0 &&
             g_force_tile == 0) {
             GemmArgs c = a;
             c.m_passes = cdiv(a.M, 64);
@@ -1016,6 +1022,7 @@ static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
             if (ok) return;
         }
     }
+    if (a.rs_in || a.rs_out) throw std::runtime_error("gemm: a deferred-RMSNorm projection did not fit the decode kernels");
     if constexpr (EPI == EPI_QKV) {
         if (a.qkv.hd == 128) {     // a wave must own a whole 128-column head: 256x256 tile as 4x2 waves of 64x128
             const int t3 = cdiv(a.M, 256) * cdiv(a.N, 256);

@@ -648,7 +648,7 @@ extern "C" int nvl_finalize(nvl_model* m) {
         m->moe_eo = dmalloc<float>(Mmax * k * H);
     }
     if (!m->f32) m->sk_part = dmalloc<float>((int64_t)m->sk_max_slices * 64 * H);
-    if (!m->f32) m->rs_part = dmalloc<float>((int64_t)cdiv(H, 16) * 64);
+    if (!m->f32) m->rs_part = dmalloc<float>((int64_t)cdiv(H, 16) * DEFER_MAX_M);
     if (m->tp > 1 || m->tp_force) m->tp_part = dmalloc<float>(Mmax * H);
     m->meta_ints = 3 * Mmax + 5 * S + m->table_cap + 16;
     NVL_HIP(hipHostMalloc((void**)&m->meta_host, (size_t)m->meta_ints * 4, hipHostMallocDefault));
@@ -1111,7 +1111,8 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
 
     // decode, RMSNorm + SwiGLU, sequential block: every residual projection carries the norm that follows it (deferred
     // RMSNorm, gemm.h), so a step keeps ONE norm launch (layer 0's, after the embedding) instead of 2L + 1
-    const bool defer_ok = g_defer_norm && !m->f32 && M <= 64 && !c.use_moe && m->tp == 1 && !m->tp_force && !m->keep_hidden &&
+    const bool big_decode = max_len == 1 && M <= g_chunk_max_m && m->group <= 16 && g_force_tile == 0;
+    const bool defer_ok = g_defer_norm && !m->f32 && (M <= 64 || (M <= DEFER_MAX_M && big_decode && g_defer_norm == 1)) && !c.use_moe && m->tp == 1 && !m->tp_force && !m->keep_hidden &&
                           c.block_style == NVL_BLOCK_SEQUENTIAL && c.norm_type == NVL_NORM_RMS &&
                           c.activation_type == NVL_ACT_SWIGLU && H % 256 == 0 && m->rs_part;
     const bool all_rows = (flags & NVL_FWD_ALL_LOGITS) != 0;
@@ -1125,7 +1126,6 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
         bool fused_dec = false;
         // a decode batch of 64 < M <= g_chunk_max_m rows keeps the decode form (64-row passes, gemm.h) and the fused
         // decode attention
-        const bool big_decode = max_len == 1 && M <= g_chunk_max_m && m->group <= 16 && g_force_tile == 0;
         if (!m->f32 && M > 64 && !big_decode) {
             // prefill: RoPE + Q/K/V placement fused into the projection's epilogue (no fp32 qkv round trip)
             GemmArgs a = mk(m->xn, H, l.w_qkv, nullptr, 0, l.b_qkv, 1.f, M, m->n_qkv, H);
@@ -1169,7 +1169,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
                 const DevTensor* nxt_w = li + 1 < m->L ? &m->layers[li + 1].t[NVL_T_ATTN_NORM_W] : &m->g[NVL_T_FINAL_NORM_W];
                 const DevTensor* nxt_b = li + 1 < m->L ? &m->layers[li + 1].t[NVL_T_ATTN_NORM_B] : &m->g[NVL_T_FINAL_NORM_B];
                 const bool defer2 = defer_ok && g_defer_norm != 3 && m->pending_slices == 0 && !nxt_b->present() &&
-                                    (li + 1 < m->L || (!all_rows && M == n_seqs));
+                                    (li + 1 < m->L || (!all_rows && M == n_seqs && M <= 64));   // (the LM head of a larger batch runs on the tile kernels)
                 resid_gemm(m, m->hbuf, m->F, l.t[NVL_T_W2].p, (const float*)l.t[NVL_T_B2].p, m->resid_alpha, M, H, m->F,
                            defer2 ? (const float*)nxt_w->p : nullptr);
                 xn_deferred = defer2;
