@@ -561,7 +561,7 @@ __device__ __forceinline__ void skinny_pass_remap(GemmArgs& p, int& bx) {
     if (p.rs_in) p.rs_in += (int64_t)z * 64 * p.rs_tiles;  // deferred RMSNorm: this group's rows of the x^2 partials
 }
 
-template <int MT, int NTW, int U, int EPI, typename OutT>
+template <int MT, int NTW, int U, int EPI, typename OutT, bool PASSES = false>
 __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* red = (f32x4*)smem;                       // [NTW][ksplit][MT][64]
@@ -570,7 +570,8 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     const int tile = wave / ksplit, kw = wave - tile * ksplit;
     const int fr = lane & 15, fg = lane >> 4;
     int bx = blockIdx.x;
-    if (p.m_passes > 1) skinny_pass_remap(p, bx);
+    if constexpr (PASSES) skinny_pass_remap(p, bx);     // (its own instantiation: rewriting the arguments costs the
+                                                        // single-group kernels a few scratch dwords otherwise)
     const int nt0 = bx * NTW;                        // first 16-row weight tile of this workgroup
     // K/32 k-steps dealt over (gridDim.y slices) x (ksplit waves) as evenly as possible (K need not divide:
     // Falcon's 4544 = 142 steps)
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 // register sets of U k-steps x (NTB weight + MT activation) fragments — for K = 2048 a wave's whole slice is in
 // flight at once.  Same deterministic in-LDS K reduction and fused epilogues as the narrow form.
 // ------------------------------------------------------------------------------------------
-template <int MT, int NTB, int U, int EPI, typename OutT>
+template <int MT, int NTB, int U, int EPI, typename OutT, bool PASSES = false>
 __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* red = (f32x4*)smem;                       // [ksplit][NTB][MT][64]
@@ -770,7 +771,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
     const int ksplit = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     int bx = blockIdx.x;
-    if (p.m_passes > 1) skinny_pass_remap(p, bx);
+    if constexpr (PASSES) skinny_pass_remap(p, bx);     // (its own instantiation: rewriting the arguments costs the
+                                                        // single-group kernels a few scratch dwords otherwise)
     const int nt0 = bx * NTB;
     const int nks = p.K >> 5, q = nks / ksplit, rr = nks - q * ksplit;
     const int my_steps = q + (kw < rr ? 1 : 0);
@@ -917,7 +919,8 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
     if (a.m_passes > 1 && (nblocks % 8 != 0 || KS != 1)) return launch_skinny_passes_serial<EPI, OutT>(st, a);
     dim3 grid(nblocks * (a.m_passes > 1 ? a.m_passes : 1), KS), block(NTW * ksplit * 64);
 #define NVL_SK(MTv, Uv) hipLaunchKernelGGL((gemm_skinny_bf16_kernel<MTv, NTW, Uv, EPI, OutT>), grid, block, lds, st, a)
-    if (MT == 1) NVL_SK(1, 4); else if (MT == 2) NVL_SK(2, 4); else NVL_SK(4, 2);
+    if (a.m_passes > 1) hipLaunchKernelGGL((gemm_skinny_bf16_kernel<4, NTW, 2, EPI, OutT, true>), grid, block, lds, st, a);
+    else if (MT == 1) NVL_SK(1, 4); else if (MT == 2) NVL_SK(2, 4); else NVL_SK(4, 2);
 #undef NVL_SK
     return true;
 }
@@ -938,18 +941,18 @@ static inline bool launch_gemm_skinny_wide(hipStream_t st, const GemmArgs& a) {
     const size_t lds = (size_t)ksplit * NTB * MT * 64 * 16;
     if (a.m_passes > 1 && groups % 8 != 0) return launch_skinny_passes_serial<EPI, OutT>(st, a);
     const int wgs = groups * (a.m_passes > 1 ? a.m_passes : 1);
-#define NVL_SKW(MTv, Uv)                                                                                               \
+#define NVL_SKW(MTv, Uv, Pv)                                                                                             \
     do {                                                                                                               \
         static bool attr = false;                                                                                      \
         if (!attr) {                                                                                                   \
-            (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_bf16_kernel<MTv, NTB, Uv, EPI, OutT>,              \
+            (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_bf16_kernel<MTv, NTB, Uv, EPI, OutT, Pv>,              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 8 * NTB * MTv * 64 * 16);            \
             attr = true;                                                                                               \
         }                                                                                                              \
-        hipLaunchKernelGGL((gemm_skinny_wide_bf16_kernel<MTv, NTB, Uv, EPI, OutT>), dim3(wgs), dim3(ksplit * 64),      \
+        hipLaunchKernelGGL((gemm_skinny_wide_bf16_kernel<MTv, NTB, Uv, EPI, OutT, Pv>), dim3(wgs), dim3(ksplit * 64),      \
                            lds, st, a);                                                                                \
     } while (0)
-    if (MT == 1) NVL_SKW(1, 4); else if (MT == 2) NVL_SKW(2, 4); else NVL_SKW(4, 2);
+    if (a.m_passes > 1) NVL_SKW(4, 2, true); else if (MT == 1) NVL_SKW(1, 4, false); else if (MT == 2) NVL_SKW(2, 4, false); else NVL_SKW(4, 2, false);
 #undef NVL_SKW
     return true;
 }
