@@ -515,25 +515,23 @@ __device__ __forceinline__ void moe_route_row(const float* __restrict__ logits_r
     const float e = (lane < E) ? expf(v - mx) : 0.f;
     const float s = wave_sum(e);
     float prob = (lane < E) ? e / s : -1.f;
-    float wsum = 0.f;
-    float my_w = 0.f;
-    int my_e = 0;
-    for (int k = 0; k < top_k; k++) {
-        float bv = prob;
-        int bi = lane;
+    // rank of this lane's probability: larger first, ties to the lower index — the order the reference's repeated
+    // argmax visits them (moe.go:75-92).  64 register broadcasts instead of top_k dependent butterfly reductions.
+    int rank = 0;
+    const int pbits = __builtin_bit_cast(int, prob);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        wsum += bv;                       // moe.go:89-92: fp32 sum in rank order
-        if (lane == k) { my_w = bv; my_e = bi; }
-        if (lane == bi) prob = -1.f;      // remove the winner
+    for (int j = 0; j < 64; j++) {
+        const float pj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pbits, j));
+        rank += (pj > prob || (pj == prob && j < lane)) ? 1 : 0;
     }
-    if (lane < top_k) {
-        ids_row[lane] = my_e;
-        w_row[lane] = my_w / wsum;        // moe.go:103
+    float wsum = 0.f;
+    for (int k = 0; k < top_k; k++) {     // moe.go:89-92: fp32 sum in rank order
+        const int src = __ffsll((unsigned long long)__ballot(rank == k)) - 1;
+        wsum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(pbits, src));
+    }
+    if (rank < top_k && lane < E) {
+        ids_row[rank] = lane;
+        w_row[rank] = prob / wsum;        // moe.go:103
     }
 }
 __global__ __launch_bounds__(256) void moe_route_kernel(const float* __restrict__ router_logits, int ld,
@@ -550,7 +548,7 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const float* __restrict_
 // the grouped GEMM's tile map, and the scatter of (token, expert) pairs into expert order — moe_route / hist / scan /
 // scatter above and the memset of the counters — as ONE single-workgroup launch.
 constexpr int MOE_PLAN_MAX_PAIRS = 2048, MOE_PLAN_MAX_E = 64;
-__global__ __launch_bounds__(256) void moe_plan_kernel(const float* __restrict__ router_logits, int ld, int rows, int E,
+__global__ __launch_bounds__(1024) void moe_plan_kernel(const float* __restrict__ router_logits, int ld, int rows, int E,
                                                        int top_k, int BM, int32_t* __restrict__ expert_ids,
                                                        float* __restrict__ expert_w, int32_t* __restrict__ seg_start,
                                                        int32_t* __restrict__ tile_map, int32_t* __restrict__ n_mtiles,
@@ -559,12 +557,12 @@ __global__ __launch_bounds__(256) void moe_plan_kernel(const float* __restrict__
     __shared__ float gw[MOE_PLAN_MAX_PAIRS];
     __shared__ int counts[MOE_PLAN_MAX_E], cursor[MOE_PLAN_MAX_E];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pairs = rows * top_k;
+    const int pairs = rows * top_k, nw = blockDim.x >> 6;
     if (threadIdx.x < MOE_PLAN_MAX_E) counts[threadIdx.x] = 0;
-    for (int r = wave; r < rows; r += 4)          // one wave per token; results stay in LDS for the phases below
+    for (int r = wave; r < rows; r += nw)         // one wave per token; results stay in LDS for the phases below
         moe_route_row(router_logits + (int64_t)r * ld, E, top_k, lane, ids + r * top_k, gw + r * top_k);
     __syncthreads();
-    for (int i = threadIdx.x; i < pairs; i += 256) {
+    for (int i = threadIdx.x; i < pairs; i += blockDim.x) {
         const int e = ids[i];
         expert_ids[i] = e;
         expert_w[i] = gw[i];
@@ -596,7 +594,7 @@ __global__ __launch_bounds__(256) void moe_plan_kernel(const float* __restrict__
     __syncthreads();
     // pairs of one expert keep their (token, rank) order: positions are handed out by a per-expert scan, not by atomics,
     // so the row order inside a segment — and with it every output bit — is the same on every run
-    for (int e = wave; e < E; e += 4) {
+    for (int e = wave; e < E; e += nw) {
         int base = cursor[e];
         for (int i0 = 0; i0 < pairs; i0 += 64) {
             const int i = i0 + lane;

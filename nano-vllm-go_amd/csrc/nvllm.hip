@@ -1015,7 +1015,7 @@ void moe(nvl_model* m, const LayerW& l, int M) {
     const bool small = !m->f32 && M <= 64 && pairs <= MOE_PLAN_MAX_PAIRS && E <= MOE_PLAN_MAX_E && g_moe_small;
     if (small) {
         KScope ks(m, KC_OTHER);
-        hipLaunchKernelGGL(moe_plan_kernel, dim3(1), dim3(256), 0, m->stream, m->router_logits, 128, M, E, k, 128, m->expert_ids,
+        hipLaunchKernelGGL(moe_plan_kernel, dim3(1), dim3(M <= 4 ? 256 : (M <= 8 ? 512 : 1024)), 0, m->stream, m->router_logits, 128, M, E, k, 128, m->expert_ids,
                            m->expert_w, m->seg_start, m->moe_tile_map, m->moe_n_mtiles, m->perm_token, m->slot_of);
         NVL_HIP(hipGetLastError());
     } else {
