@@ -1023,10 +1023,10 @@ void moe(nvl_model* m, const LayerW& l, int M) {
         NVL_HIP(hipMemsetAsync(m->moe_counts, 0, (size_t)E * 4, m->stream));
         hipLaunchKernelGGL(moe_route_kernel, dim3(cdiv(M, 4)), dim3(256), 0, m->stream, m->router_logits, 128, M, E, k,
                            m->expert_ids, m->expert_w);
-        hipLaunchKernelGGL(moe_hist_kernel, dim3(cdiv(pairs, 256)), dim3(256), 0, m->stream, m->expert_ids, pairs, m->moe_counts);
+        hipLaunchKernelGGL(moe_hist_kernel, dim3(cdiv(pairs, MOE_PAIRS_PER_WG)), dim3(256), 0, m->stream, m->expert_ids, pairs, m->moe_counts);
         hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(64), 0, m->stream, m->moe_counts, E, 128, m->seg_start, m->moe_cursor,
                            m->moe_tile_map, m->moe_n_mtiles);
-        hipLaunchKernelGGL(moe_scatter_kernel, dim3(cdiv(pairs, 256)), dim3(256), 0, m->stream, m->expert_ids, pairs, k,
+        hipLaunchKernelGGL(moe_scatter_kernel, dim3(cdiv(pairs, MOE_PAIRS_PER_WG)), dim3(256), 0, m->stream, m->expert_ids, pairs, k,
                            m->moe_cursor, m->perm_token, m->slot_of);
         NVL_HIP(hipGetLastError());
     }

@@ -229,18 +229,27 @@ def test_ffn(gpu, oracle, swiglu, precision):
     assert rel_err(got, want) <= (5e-5 if precision == "f32" else BF16_TOL)
 
 
+@pytest.mark.parametrize("rows,E,k", [(11, 8, 2), (700, 32, 4),      # 2800 pairs: several workgroups in the histogram / scatter
+                                      (40, 64, 8)])                   # decode-sized: the single-launch plan, E = 64
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
-def test_moe(gpu, oracle, precision):
-    r = rng(9)
-    rows, H, E, k, I = 11, 128, 8, 2, 64
+def test_moe(gpu, oracle, precision, rows, E, k):
+    r = rng(9 + rows)
+    H, I = 128, 64
     x = r.standard_normal((rows, H), dtype=np.float32)
     router = r.standard_normal((H, E), dtype=np.float32) * 0.3
     w_in = r.standard_normal((E, 2 * I, H), dtype=np.float32) * 0.1
     w_out = r.standard_normal((E, H, I), dtype=np.float32) * 0.1
     want = oracle.moe(x, router, w_in, w_out, k)
     got = gpu.ops.moe_forward(x, router, w_in, w_out, k, precision=precision)
-    # bf16 router logits can reorder near-tied experts; the fixture's margins are far above that
-    assert rel_err(got, want) <= (5e-5 if precision == "f32" else 3e-2)
+    if precision == "f32":
+        assert rel_err(got, want) <= 5e-5
+        return
+    # bf16 router logits can swap near-tied experts at the top-k boundary: check the rows whose k-th and (k+1)-th
+    # logits are further apart than the rounding of the bf16 router GEMM (the 11-row fixture's rows all are)
+    logits = np.sort(x.astype(np.float64) @ router.astype(np.float64), axis=1)[:, ::-1]
+    clear = (logits[:, k - 1] - logits[:, k]) > 0.05
+    assert clear.mean() > 0.5 and (rows > 11 or clear.all())
+    assert rel_err(got[clear], want[clear]) <= 3e-2
 
 
 def test_argmax_first_max_tie_rule(gpu, oracle):
