@@ -650,6 +650,20 @@ __global__ __launch_bounds__(256) void moe_hist_kernel(const int32_t* __restrict
     __syncthreads();
     if (threadIdx.x < 64 && lc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], lc[threadIdx.x]);
 }
+// prefill: rows of the fragment-major activation matrix copied into expert order (dst row i = src row perm[i]), one
+// workgroup per 16 destination rows; a wave moves whole 1-KiB operand blocks (coalesced stores, 16-byte gathers)
+__global__ __launch_bounds__(256) void moe_gather_fm_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ perm,
+                                                            bf16_t* __restrict__ dst, int n_rows, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 16 + (lane & 15), fg = lane >> 4;
+    const int nks = K >> 5;
+    if (r >= n_rows) return;                       // rows past the end of the last tile are never stored by the GEMM
+    const int tok = perm[r];
+    const bf16_t* s = src + ((int64_t)(tok >> 4) * nks * 64 + (tok & 15) + 16 * fg) * 8;
+    bf16_t* d = dst + ((int64_t)blockIdx.x * nks * 64 + lane) * 8;
+    for (int ks = wave; ks < nks; ks += 4)
+        *(bf16x8*)(d + (int64_t)ks * 512) = *(const bf16x8*)(s + (int64_t)ks * 512);
+}
 __global__ __launch_bounds__(64) void moe_scan_kernel(const int32_t* __restrict__ counts, int E, int BM,
                                                       int32_t* __restrict__ seg_start, int32_t* __restrict__ cursor,
                                                       int32_t* __restrict__ tile_map, int32_t* __restrict__ n_mtiles) {

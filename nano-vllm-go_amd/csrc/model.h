@@ -105,6 +105,7 @@ struct nvl_model {
     int32_t* expert_ids = nullptr; float* expert_w = nullptr;
     int32_t *seg_start = nullptr, *perm_token = nullptr, *slot_of = nullptr;
     float* moe_eo = nullptr;          // [Mmax*k][H]
+    void* moe_xg = nullptr;           // bf16: the normed rows in expert order, fragment-major [round_up(Mmax*k, 64)][H] (prefill)
     int32_t *moe_counts = nullptr, *moe_cursor = nullptr, *moe_tile_map = nullptr, *moe_n_mtiles = nullptr;
     // decode split-K: partial slices of the last residual GEMM, consumed by the next norm launch
     float* rs_part = nullptr;    // deferred RMSNorm: [H/16][64] partial sums of x^2 (gemm.h)

@@ -240,7 +240,7 @@ extern "C" void nvl_destroy(nvl_model* m) {
     dfree(m->rope_cos); dfree(m->rope_sin); dfree(m->kcache); dfree(m->vcache);
     dfree(m->x); dfree(m->xn); dfree(m->qkv); dfree(m->q); dfree(m->attn_out); dfree(m->hbuf); dfree(m->h2);
     dfree(m->xn_last); dfree(m->logits); dfree(m->argmax_dev); dfree(m->argmax_pval); dfree(m->argmax_pidx); dfree(m->router_logits); dfree(m->expert_ids);
-    dfree(m->expert_w); dfree(m->seg_start); dfree(m->moe_counts); dfree(m->moe_cursor); dfree(m->moe_tile_map); dfree(m->moe_n_mtiles); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo);
+    dfree(m->expert_w); dfree(m->seg_start); dfree(m->moe_counts); dfree(m->moe_cursor); dfree(m->moe_tile_map); dfree(m->moe_n_mtiles); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo); dfree(m->moe_xg);
     dfree(m->meta_dev); dfree(m->hidden); dfree(m->sk_part); dfree(m->tp_part); dfree(m->ring); dfree(m->rs_part);
     free_sample_bufs(m->samp);
     dfree(m->samp_hist); dfree(m->samp_hist_len); dfree(m->samp_u_steps);
@@ -646,6 +646,7 @@ extern "C" int nvl_finalize(nvl_model* m) {
         m->perm_token = dmalloc<int32_t>(Mmax * k);
         m->slot_of = dmalloc<int32_t>(Mmax * k);
         m->moe_eo = dmalloc<float>(Mmax * k * H);
+        if (!m->f32) m->moe_xg = dmalloc_bytes(round_up(Mmax * k, 64) * H * 2);
     }
     if (!m->f32) m->sk_part = dmalloc<float>((int64_t)m->sk_max_slices * 64 * H);
     if (!m->f32) m->rs_part = dmalloc<float>((int64_t)cdiv(H, 16) * DEFER_MAX_M);
@@ -933,6 +934,7 @@ void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
 // Prefill and the fp32 mode fuse the add into the GEMM epilogue.  Decode-sized batches split K over
 // `slices` workgroups per column block so that all 256 CUs stream weights (a 2048-column projection has
 // only 128 column blocks), and leave the add to the norm kernel that always follows (PendingResid).
+static int g_moe_gather = 1;   // nvl_set_tuning key 16: prefill MoE gathers the token rows into expert order before the grouped GEMM (0 = per-lane gather inside it)
 static int g_moe_small = 1;    // nvl_set_tuning key 8: fused MoE planning launch + combine folded into the next norm (0 = off)
 static int g_decode_seam = 1;  // nvl_set_tuning key 7: decode_seam_kernel in nvl_decode_greedy (0 = separate kernels)
 static int g_defer_norm = 1;   // nvl_set_tuning key 3: deferred RMSNorm between O-proj and FFN-up in decode (0 = off)
@@ -1054,6 +1056,16 @@ void moe(nvl_model* m, const LayerW& l, int M) {
     } else {
         GemmArgs a = mk(m->xn, H, l.moe_in, m->hbuf, I, nullptr, 1.f, max_mtiles, 2 * I, H);
         a.a_rows = m->perm_token; a.tile_map = m->moe_tile_map; a.n_mtiles = m->moe_n_mtiles;
+        if (!small && m->moe_xg && g_moe_gather) {
+            // prefill: every m-tile's rows would be re-gathered 16 bytes at a time by each of its 2I/128 column tiles
+            // (64 cache lines per load instruction); copy them into expert order once, then the GEMM streams whole
+            // 1-KiB operand blocks (Granite-1B, 16384 tokens: expert-up 1119 -> ? us per layer)
+            KScope ks(m, KC_OTHER);
+            hipLaunchKernelGGL(moe_gather_fm_kernel, dim3(cdiv(pairs, 16)), dim3(256), 0, m->stream, (const bf16_t*)m->xn,
+                               m->perm_token, (bf16_t*)m->moe_xg, pairs, H);
+            NVL_HIP(hipGetLastError());
+            a.A = m->moe_xg; a.a_rows = nullptr;
+        }
         a.w_expert_stride = (int64_t)2 * I * H;
         gemm(m, EPI_SWIGLU, false, a, 2.0 * pairs * 2 * I * H);
         GemmArgs d = mk(m->hbuf, I, l.t[NVL_T_MOE_OUT].p, m->moe_eo, H, nullptr, 1.f, max_mtiles, H, I);

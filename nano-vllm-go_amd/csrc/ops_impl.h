@@ -293,6 +293,7 @@ extern "C" int nvl_op_moe(int device, int precision, const float* x, const float
     m.moe_tile_map = (int32_t*)cx.alloc(16 * (cdiv(pairs, 128) + n_experts)); m.moe_n_mtiles = (int32_t*)cx.alloc(16);
     m.perm_token = (int32_t*)cx.alloc(pairs * 4); m.slot_of = (int32_t*)cx.alloc(pairs * 4);
     m.moe_eo = (float*)cx.alloc(pairs * hidden * 4);
+    if (!m.f32) m.moe_xg = cx.alloc(round_up(pairs, 64) * hidden * 2);
     m.hbuf = cx.alloc(round_up(pairs, 64) * inter * (int64_t)m.wsize);
     if (m.f32) m.h2 = (float*)cx.alloc(pairs * 2 * inter * 4);
     m.x = (float*)cx.alloc((int64_t)rows * hidden * 4);
@@ -302,7 +303,7 @@ extern "C" int nvl_op_moe(int device, int precision, const float* x, const float
     cx.down(y, m.x, (int64_t)rows * hidden);
     l.moe_in = nullptr; l.t[NVL_T_ROUTER].p = nullptr; l.t[NVL_T_MOE_OUT].p = nullptr;
     m.xn = m.hbuf = nullptr; m.h2 = nullptr; m.x = nullptr; m.router_logits = nullptr; m.expert_ids = nullptr;
-    m.expert_w = nullptr; m.seg_start = m.perm_token = m.slot_of = nullptr; m.moe_eo = nullptr;
+    m.expert_w = nullptr; m.seg_start = m.perm_token = m.slot_of = nullptr; m.moe_eo = nullptr; m.moe_xg = nullptr;
     m.moe_counts = m.moe_cursor = m.moe_tile_map = m.moe_n_mtiles = nullptr;
     return NVL_OK;
     OP_CATCH
@@ -395,6 +396,7 @@ extern "C" int nvl_bench_gemm(int device, int M, int N, int K, int epi, int forc
 extern "C" int nvl_set_tuning(int key, int value) {
     if (key == 0) { const int old = g_force_tile; g_force_tile = value; return old; }
     if (key == 1) { const int old = g_sk_slices; g_sk_slices = value; return old; }
+    if (key == 16) { const int old = g_moe_gather; g_moe_gather = value; return old; }
     if (key == 15) { const int old = g_attn_nw; g_attn_nw = value; return old; }
     if (key == 14) { const int old = g_chunk_all_m; g_chunk_all_m = value; return old; }
     if (key == 13) { const int old = g_pass_interleave; g_pass_interleave = value; return old; }
