@@ -356,7 +356,10 @@ int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int 
  * with 128 query rows per workgroup (0 never, 1 automatic, 2 always).  keys 11-14: decode batches of 65..512 rows (key 11, default 512; 64 = off) run the
  * projections whose 128x128 tile grid has fewer than key 12 (160) workgroups as ceil(M/64) groups of 64 rows of the
  * decode GEMM form, in one launch interleaved over the weight blocks (key 13 = 1) or one launch per group (0); up to
- * key 14 rows (64) every projection does.  Returns the previous value. */
+ * key 14 rows (64) every projection does.  key 15: waves per decode-attention workgroup (0 = from context length and
+ * grid size, 2, 4, 8).  key 16: prefill MoE copies the token rows into expert order before the grouped GEMM (1, default)
+ * or gathers them per lane inside it (0).  key 17: rows per m-tile of the grouped MoE GEMMs (128 default, 256).
+ * Returns the previous value. */
 int nvl_set_tuning(int key, int value);
 
 #ifdef __cplusplus

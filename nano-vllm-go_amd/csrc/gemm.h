@@ -71,6 +71,7 @@ struct GemmArgs {
     const int32_t* tile_map;
     const int32_t* n_mtiles;
     int64_t w_expert_stride;
+    int grp_bm;             // rows per m-tile of the grouped launch (128, or 256: the 256x128 three-stage instance)
     QkvEpi qkv;             // EPI_QKV
     // decode kernel, EPI_RESID only: K split over gridDim.y = sk_slices workgroups per column block.  Each
     // writes its fp32 partial tile to sk_part[slice][m][n] (ld = N) with plain stores; the NEXT kernel in the
@@ -994,6 +995,18 @@ static inline double cu_fill(int tiles, int per_cu) {
 
 template <int EPI, typename OutT>
 static inline void launch_gemm_grouped(hipStream_t st, const GemmArgs& a, int max_mtiles) {
+    if (a.grp_bm == 256) {      // prefill MoE with long expert segments: 256-row m-tiles, three stages
+        constexpr int lds3 = gemm_lds_bytes<256, 128, 3>();
+        static bool attr3 = false;
+        if (!attr3) {
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<256, 128, 4, 2, 3, EPI, OutT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+            attr3 = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_kernel<256, 128, 4, 2, 3, EPI, OutT>), dim3(cdiv(a.N, 128) * max_mtiles), dim3(512),
+                           lds3, st, a);
+        return;
+    }
     constexpr int lds = gemm_lds_bytes<128, 128, 2>();
     static bool attr_set = false;
     if (!attr_set) {

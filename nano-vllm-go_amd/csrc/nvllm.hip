@@ -934,6 +934,7 @@ void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
 // Prefill and the fp32 mode fuse the add into the GEMM epilogue.  Decode-sized batches split K over
 // `slices` workgroups per column block so that all 256 CUs stream weights (a 2048-column projection has
 // only 128 column blocks), and leave the add to the norm kernel that always follows (PendingResid).
+static int g_moe_bm = 0;       // nvl_set_tuning key 17: m-tile rows of the grouped MoE GEMMs (0 / 128: 128, 256)
 static int g_moe_gather = 1;   // nvl_set_tuning key 16: prefill MoE gathers the token rows into expert order before the grouped GEMM (0 = per-lane gather inside it)
 static int g_moe_small = 1;    // nvl_set_tuning key 8: fused MoE planning launch + combine folded into the next norm (0 = off)
 static int g_decode_seam = 1;  // nvl_set_tuning key 7: decode_seam_kernel in nvl_decode_greedy (0 = separate kernels)
@@ -1015,6 +1016,9 @@ void moe(nvl_model* m, const LayerW& l, int M) {
     gemm(m, EPI_STORE, true, mk(m->xn, H, l.t[NVL_T_ROUTER].p, m->router_logits, 128, nullptr, 1.f, M, E, H));
     // decode-sized batches: one planning launch, and the weighted combine rides on the norm that follows
     const bool small = !m->f32 && M <= 64 && pairs <= MOE_PLAN_MAX_PAIRS && E <= MOE_PLAN_MAX_E && g_moe_small;
+    // m-tile height of the grouped GEMMs: 128 rows; the 256x128 three-stage instance stays a tuning option (Granite-1B,
+    // 4096 rows per expert: 441 K vs 450 K prefill tok/s)
+    const int BM = (!m->f32 && !small && g_moe_bm == 256) ? 256 : 128;
     if (small) {
         KScope ks(m, KC_OTHER);
         hipLaunchKernelGGL(moe_plan_kernel, dim3(1), dim3(M <= 4 ? 256 : (M <= 8 ? 512 : 1024)), 0, m->stream, m->router_logits, 128, M, E, k, 128, m->expert_ids,
@@ -1026,13 +1030,13 @@ void moe(nvl_model* m, const LayerW& l, int M) {
         hipLaunchKernelGGL(moe_route_kernel, dim3(cdiv(M, 4)), dim3(256), 0, m->stream, m->router_logits, 128, M, E, k,
                            m->expert_ids, m->expert_w);
         hipLaunchKernelGGL(moe_hist_kernel, dim3(cdiv(pairs, MOE_PAIRS_PER_WG)), dim3(256), 0, m->stream, m->expert_ids, pairs, m->moe_counts);
-        hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(64), 0, m->stream, m->moe_counts, E, 128, m->seg_start, m->moe_cursor,
+        hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(64), 0, m->stream, m->moe_counts, E, BM, m->seg_start, m->moe_cursor,
                            m->moe_tile_map, m->moe_n_mtiles);
         hipLaunchKernelGGL(moe_scatter_kernel, dim3(cdiv(pairs, MOE_PAIRS_PER_WG)), dim3(256), 0, m->stream, m->expert_ids, pairs, k,
                            m->moe_cursor, m->perm_token, m->slot_of);
         NVL_HIP(hipGetLastError());
     }
-    const int max_mtiles = cdiv(pairs, 128) + E;      // every expert may end on a partial tile
+    const int max_mtiles = cdiv(pairs, BM) + E;      // every expert may end on a partial tile
     if (m->f32) {
         for (int e = 0; e < E; e++) {   // grid bounded by M: a token picks an expert at most once; surplus blocks exit
             const char* win = (const char*)l.moe_in + (size_t)e * 2 * I * H * m->wsize;
@@ -1066,10 +1070,10 @@ void moe(nvl_model* m, const LayerW& l, int M) {
             NVL_HIP(hipGetLastError());
             a.A = m->moe_xg; a.a_rows = nullptr;
         }
-        a.w_expert_stride = (int64_t)2 * I * H;
+        a.w_expert_stride = (int64_t)2 * I * H; a.grp_bm = BM;
         gemm(m, EPI_SWIGLU, false, a, 2.0 * pairs * 2 * I * H);
         GemmArgs d = mk(m->hbuf, I, l.t[NVL_T_MOE_OUT].p, m->moe_eo, H, nullptr, 1.f, max_mtiles, H, I);
-        d.tile_map = m->moe_tile_map; d.n_mtiles = m->moe_n_mtiles; d.w_expert_stride = (int64_t)H * I;
+        d.tile_map = m->moe_tile_map; d.n_mtiles = m->moe_n_mtiles; d.w_expert_stride = (int64_t)H * I; d.grp_bm = BM;
         gemm(m, EPI_STORE, true, d, 2.0 * pairs * H * I);
     }
     if (small && !m->keep_hidden && m->pending_slices == 0 && H % 4 == 0 && H <= 1024 * NORM_ROW_MAXCH) {

@@ -241,6 +241,15 @@ def test_moe(gpu, oracle, precision, rows, E, k):
     w_out = r.standard_normal((E, H, I), dtype=np.float32) * 0.1
     want = oracle.moe(x, router, w_in, w_out, k)
     got = gpu.ops.moe_forward(x, router, w_in, w_out, k, precision=precision)
+    if precision == "bf16" and rows > 64:
+        # the prefill variants: 256-row m-tiles (key 17) and the in-GEMM row gather (key 16 = 0) give the same rows
+        for key, val in ((17, 256), (16, 0)):
+            old = gpu.lib().nvl_set_tuning(key, val)
+            try:
+                alt = gpu.ops.moe_forward(x, router, w_in, w_out, k, precision=precision)
+            finally:
+                gpu.lib().nvl_set_tuning(key, old)
+            assert np.array_equal(alt, got), (key, val)
     if precision == "f32":
         assert rel_err(got, want) <= 5e-5
         return
