@@ -56,7 +56,8 @@ def test_matmul_prefill_tile_kernels(gpu, oracle, tile, m, k, n):
 
 
 @pytest.mark.parametrize("interleave", [1, 0])
-@pytest.mark.parametrize("m,k,n", [(65, 256, 128), (130, 2048, 2048), (200, 512, 3072), (512, 192, 1003), (96, 128, 200)])
+@pytest.mark.parametrize("m,k,n", [(65, 256, 128), (130, 2048, 2048), (200, 512, 3072), (512, 192, 1003), (96, 128, 200),
+                                   (100, 256, 16384)])     # the wide-N form in groups
 def test_matmul_row_groups_of_decode_form(gpu, oracle, interleave, m, k, n):
     """64 < M <= 512 with a small tile grid: ceil(M/64) groups of 64 activation rows of the decode kernels — one
     interleaved launch when the weight-block count is a multiple of 8 (n = 128, 2048, 3072), one launch per group
@@ -292,11 +293,12 @@ def test_matmul_decode_forms(gpu, oracle, form, m, k, n):
     assert np.array_equal(goti, oracle.matmul(ai, bi))
 
 
+@pytest.mark.parametrize("rows", [20, 100, 128])     # 100, 128: two 64-row groups in one launch (the second ragged / full)
 @pytest.mark.parametrize("swiglu", [True, False])
-def test_ffn_wide_decode_form(gpu, oracle, swiglu):
+def test_ffn_wide_decode_form(gpu, oracle, swiglu, rows):
     """SwiGLU / GELU epilogues of the wide-N decode form (F large enough that its 64-row groups fill the chip)."""
-    r = rng(11)
-    rows, H, F = 20, 64, 8192 if swiglu else 16384
+    r = rng(11 + rows)
+    H, F = 64, 8192 if swiglu else 16384
     x = r.standard_normal((rows, H), dtype=np.float32)
     w1 = r.standard_normal((H, 2 * F if swiglu else F), dtype=np.float32) * 0.1
     w2 = r.standard_normal((F, H), dtype=np.float32) * 0.02
