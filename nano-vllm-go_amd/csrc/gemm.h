@@ -560,6 +560,11 @@ __device__ __forceinline__ void skinny_pass_remap(GemmArgs& p, int& bx) {
     p.c_row0 += z * 64;
     p.M = min(64, p.M - z * 64);                           // the last group may be ragged (operands are padded to 64 rows)
     if (p.rs_in) p.rs_in += (int64_t)z * 64 * p.rs_tiles;  // deferred RMSNorm: this group's rows of the x^2 partials
+    if (p.rs_out) {                                        // ... and on the producer side (its epilogue indexes rows locally)
+        p.C = (float*)p.C + (int64_t)z * 64 * p.ldc;
+        p.nrm_xn += (int64_t)z * 64 * p.N;
+        p.rs_out += (int64_t)z * 64 * (p.N >> 4);
+    }
 }
 
 template <int MT, int NTW, int U, int EPI, typename OutT, bool PASSES = false>
@@ -875,8 +880,9 @@ static int g_force_tile = 0;                      // 0 automatic, 1: 128x128x2st
 
 template <int EPI, typename OutT>
 static inline bool launch_gemm_skinny_bf16(hipStream_t st, const GemmArgs& a);
-constexpr int DEFER_MAX_M = 64;     // deferred RMSNorm (decode): rows of the x^2 partial buffer.  128 was measured (B=128: the
-                                    // producer's one-workgroup-per-16-rows grid costs more than the 32 norm launches save: -13 %)
+constexpr int DEFER_MAX_M = 128;    // deferred RMSNorm (decode): rows of the x^2 partial buffer.  Above 64 rows the producer
+                                    // runs as 64-row groups like every narrow projection (one workgroup per 16-row tile
+                                    // was measured at M = 128: -13 %); above 128 rows FFN-up belongs on the tile kernels
 static inline int skinny_rows(const GemmArgs& a) { return a.m_passes > 1 && a.M > 64 ? 64 : a.M; }   // rows a workgroup covers
 // the groups of 64 rows as separate launches (weight-block count not a multiple of 8, or key 13 = 0)
 template <int EPI, typename OutT>
@@ -888,6 +894,10 @@ static inline bool launch_skinny_passes_serial(hipStream_t st, const GemmArgs& a
         c.M = a.M - r0 < 64 ? a.M - r0 : 64;
         c.c_row0 = a.c_row0 + r0;
         if (a.rs_in) c.rs_in = a.rs_in + (int64_t)r0 * a.rs_tiles;
+        if (a.rs_out) {
+            c.C = (float*)a.C + (int64_t)r0 * a.ldc; c.nrm_xn = a.nrm_xn + (int64_t)r0 * a.N;
+            c.rs_out = a.rs_out + (int64_t)r0 * (a.N >> 4);
+        }
         if (!launch_gemm_skinny_bf16<EPI, OutT>(st, c)) return false;
     }
     return true;
@@ -900,7 +910,7 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
     const int U = MT <= 2 ? 4 : 2;                       // register budget: (1+MT)*U*2 fragments
     const int nblocks = cdiv(cdiv(a.N, 16), NTW);        // weight rows are padded to 128: all tiles exist
     const int KS = (EPI == EPI_RESID && a.sk_part && a.sk_slices > 1) ? a.sk_slices : 1;
-    if (EPI == EPI_RESID && a.m_split && a.rs_out && NTW == 1) {
+    if (EPI == EPI_RESID && a.m_split && a.rs_out && NTW == 1 && a.m_passes <= 1) {
         // deferred-norm residual projection: one workgroup per (weight tile, 16-row activation tile), all of K each
         int ks = g_msplit_ks;
         while (ks > 1 && (a.K >> 5) / ks < 4) ks >>= 1;
@@ -960,8 +970,7 @@ static inline bool launch_gemm_skinny_wide(hipStream_t st, const GemmArgs& a) {
 template <int EPI, typename OutT>
 static inline bool launch_gemm_skinny_bf16(hipStream_t st, const GemmArgs& a) {
     if (EPI == EPI_QKV) return false;               // prefill-only epilogue (a decode workgroup owns 16 columns, not a head)
-    const bool defer_producer = EPI == EPI_RESID && a.m_split && a.rs_out && a.M <= DEFER_MAX_M;   // one workgroup per 16-row tile
-    if ((skinny_rows(a) > 64 && !defer_producer) || a.a_rows || a.seg || a.tile_map) return false;
+    if (skinny_rows(a) > 64 || a.a_rows || a.seg || a.tile_map) return false;
     if constexpr (EPI == EPI_SWIGLU || EPI == EPI_STORE || EPI == EPI_GELU) {
         // wide-N form once its 64-row groups fill the chip (g_force_ntw: 8 forces it, 1/2/4 force the narrow form)
         const bool wide_ok = skinny_rows(a) > 16 && cdiv(a.N, 64) >= 256 && !a.sk_part;   // M <= 16: the narrow form streams as fast
@@ -1029,7 +1038,7 @@ static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
         // weights cross HBM once.  Only the narrow projections (QKV, O, FFN-down) do; FFN-up and the LM head have enough
         // tiles (g_chunk_all_m: below it every projection would).
         const bool few_tiles = cdiv(a.M, 128) * cdiv(a.N, 128) < g_chunk_min_tiles;
-        if (a.M > 64 && a.M <= g_chunk_max_m && (a.M <= g_chunk_all_m || few_tiles || a.rs_in) && !a.a_rows && !a.seg && !a.sk_part && !a.rs_out && a.K % 32 == 0 &&
+        if (a.M > 64 && a.M <= g_chunk_max_m && (a.M <= g_chunk_all_m || few_tiles || a.rs_in || a.rs_out) && !a.a_rows && !a.seg && !a.sk_part && a.K % 32 == 0 &&
             g_force_tile == 0) {
             GemmArgs c = a;
             c.m_passes = cdiv(a.M, 64);
