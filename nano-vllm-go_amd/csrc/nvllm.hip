@@ -934,6 +934,7 @@ void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
 // Prefill and the fp32 mode fuse the add into the GEMM epilogue.  Decode-sized batches split K over
 // `slices` workgroups per column block so that all 256 CUs stream weights (a 2048-column projection has
 // only 128 column blocks), and leave the add to the norm kernel that always follows (PendingResid).
+static int g_qkv_store_max_m = 256;   // nvl_set_tuning key 18: largest prefill batch whose QKV projection runs as decode-form groups + rope_kv_kernel
 static int g_moe_bm = 0;       // nvl_set_tuning key 17: m-tile rows of the grouped MoE GEMMs (0 / 128: 128, 256)
 static int g_moe_gather = 1;   // nvl_set_tuning key 16: prefill MoE gathers the token rows into expert order before the grouped GEMM (0 = per-lane gather inside it)
 static int g_moe_small = 1;    // nvl_set_tuning key 8: fused MoE planning launch + combine folded into the next norm (0 = off)
@@ -1142,7 +1143,10 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
         bool fused_dec = false;
         // a decode batch of 64 < M <= g_chunk_max_m rows keeps the decode form (64-row passes, gemm.h) and the fused
         // decode attention
-        if (!m->f32 && M > 64 && !big_decode) {
+        // short prefill batches (65..g_qkv_store_max_m tokens): the fused-epilogue tile kernel would run on M/128 * 24
+        // workgroups; the decode form + rope_kv_kernel is faster there
+        const bool short_prefill = max_len > 1 && M <= g_qkv_store_max_m && M <= g_chunk_max_m && g_force_tile == 0;
+        if (!m->f32 && M > 64 && !big_decode && !short_prefill) {
             // prefill: RoPE + Q/K/V placement fused into the projection's epilogue (no fp32 qkv round trip)
             GemmArgs a = mk(m->xn, H, l.w_qkv, nullptr, 0, l.b_qkv, 1.f, M, m->n_qkv, H);
             a.qkv.tok_pos = md.tok_pos; a.qkv.tok_tbl = md.tok_tbl; a.qkv.blk_table = md.blk_table; a.qkv.cos_t = m->rope_cos; a.qkv.sin_t = m->rope_sin;

@@ -27,8 +27,12 @@ def build(gpu, oracle, family, precision, peaked=0.0, **over):
 
 @pytest.mark.parametrize("family", FAMILIES)
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
-@pytest.mark.parametrize("ntok", [37, 131])      # 37: decode-sized kernels (M <= 64); 131: the prefill tile kernels + fused QKV epilogue
-def test_prefill_logits_hidden_and_kv(gpu, oracle, family, precision, ntok):
+@pytest.mark.parametrize("ntok,qkv_store", [(37, 256),     # decode-sized kernels (M <= 64)
+                                            (131, 64),     # the prefill tile kernels + fused QKV epilogue
+                                            (131, 256)])   # short prefill: QKV as decode-form groups + rope_kv_kernel (key 18)
+def test_prefill_logits_hidden_and_kv(gpu, oracle, family, precision, ntok, qkv_store, request):
+    old18 = gpu.lib().nvl_set_tuning(18, qkv_store)
+    request.addfinalizer(lambda: gpu.lib().nvl_set_tuning(18, old18))
     cfg, om, hm = build(gpu, oracle, family, precision)
     toks = np.random.default_rng(1).integers(0, cfg["vocab_size"], ntok).tolist()
     kv = om.new_cache()
@@ -168,10 +172,13 @@ def test_errors_instead_of_panics(gpu, oracle):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
-@pytest.mark.parametrize("ntok", [29, 150])
-def test_head_dim_128(gpu, oracle, precision, ntok):
+@pytest.mark.parametrize("ntok,qkv_store", [(29, 256), (150, 64), (150, 256)])
+def test_head_dim_128(gpu, oracle, precision, ntok, qkv_store, request):
     """Llama-3-8B's head geometry (head_dim 128, GQA) on a small model: prefill (fused QKV epilogue on the 4x2-wave
-    256x256 instance), decode (fused RoPE + attention), KV contents."""
+    256x256 instance with key 18 = 64, decode-form QKV + rope_kv_kernel otherwise), decode (fused RoPE + attention),
+    KV contents."""
+    old18 = gpu.lib().nvl_set_tuning(18, qkv_store)
+    request.addfinalizer(lambda: gpu.lib().nvl_set_tuning(18, old18))
     cfg = gpu.synth.tiny_config("llama", head_dim=128, hidden=256, num_heads=4, num_kv_heads=2, ffn_dim=512)
     w = gpu.synth.make_weights(cfg, seed=13, scale=0.05)
     om = oracle.OracleModel(cfg, w)
