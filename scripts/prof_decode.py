@@ -1,7 +1,7 @@
 """Aggregate a rocprofv3 kernel trace of bench.py by kernel, separately for the decode phase
 (everything after the last prefill attention launch)."""
 import collections, csv, glob, sys
-f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
+f = (glob.glob(sys.argv[1] + "/*/*kernel_trace.csv") + glob.glob(sys.argv[1] + "/*kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 last_prefill = max(i for i, r in enumerate(rows) if "attn_bf16_kernel" in r["Kernel_Name"])
