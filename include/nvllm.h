@@ -359,6 +359,7 @@ int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int 
  * key 14 rows (64) every projection does.  key 15: waves per decode-attention workgroup (0 = from context length and
  * grid size, 2, 4, 8).  key 16: prefill MoE copies the token rows into expert order before the grouped GEMM (1, default)
  * or gathers them per lane inside it (0).  key 17: rows per m-tile of the grouped MoE GEMMs (128 default, 256).
+ * key 19: decode-sized MoE batches run the grouped GEMMs on the four-stage 128x128 instance (1, default) or two stages (0).
  * key 18: largest prefill batch (tokens) whose QKV projection runs as decode-form groups + rope_kv_kernel instead of the
  * fused-epilogue tile kernel (default 256: +5 % at 128 tokens, +1 % at 256, -4 % at 512).
  * Returns the previous value. */

@@ -72,6 +72,7 @@ struct GemmArgs {
     const int32_t* n_mtiles;
     int64_t w_expert_stride;
     int grp_bm;             // rows per m-tile of the grouped launch (128, or 256: the 256x128 three-stage instance)
+    int grp_deep;           // grouped launch on the four-stage 128x128 instance (decode-sized MoE batches)
     QkvEpi qkv;             // EPI_QKV
     // decode kernel, EPI_RESID only: K split over gridDim.y = sk_slices workgroups per column block.  Each
     // writes its fp32 partial tile to sk_part[slice][m][n] (ld = N) with plain stores; the NEXT kernel in the
@@ -325,9 +326,11 @@ void gemm_bf16_kernel(GemmArgs p) {
     auto wait_tiles_in_flight = [&](int tiles) {   // s_waitcnt needs an immediate
         if (tiles <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (PW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (tiles == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // four stages: two younger tiles of 8 loads each
     };
     static_assert(STAGES == 2 || PW == 6 || PW == 8, "add the immediate for this PW");
+    static_assert(STAGES <= 3 || PW == 8, "four stages: only the PW = 8 immediates exist");
 
     // ---- fragment reads: stage image [A row-tile][k-step][lane][16 B] then [W row-tile][k-step][lane][16 B]
     const int a_blk_off = wm * TM * 2048 + lane * 16;                 // activation rows -> MFMA B operand (output col m)
@@ -1014,6 +1017,18 @@ static inline void launch_gemm_grouped(hipStream_t st, const GemmArgs& a, int ma
         }
         hipLaunchKernelGGL((gemm_bf16_kernel<256, 128, 4, 2, 3, EPI, OutT>), dim3(cdiv(a.N, 128) * max_mtiles), dim3(512),
                            lds3, st, a);
+        return;
+    }
+    if (a.grp_deep) {           // decode MoE: a handful of rows per expert, one workgroup per CU streaming 128 weight rows —
+        constexpr int lds4 = gemm_lds_bytes<128, 128, 4>();   // latency-bound with two stages (16 K tiles, one round trip each)
+        static bool attr4 = false;
+        if (!attr4) {
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<128, 128, 2, 2, 4, EPI, OutT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+            attr4 = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, 2, 4, EPI, OutT>), dim3(cdiv(a.N, 128) * max_mtiles), dim3(256),
+                           lds4, st, a);
         return;
     }
     constexpr int lds = gemm_lds_bytes<128, 128, 2>();

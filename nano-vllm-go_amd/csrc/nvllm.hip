@@ -935,6 +935,7 @@ void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
 // `slices` workgroups per column block so that all 256 CUs stream weights (a 2048-column projection has
 // only 128 column blocks), and leave the add to the norm kernel that always follows (PendingResid).
 static int g_qkv_store_max_m = 256;   // nvl_set_tuning key 18: largest prefill batch whose QKV projection runs as decode-form groups + rope_kv_kernel
+static int g_moe_deep = 1;     // nvl_set_tuning key 19: four-stage grouped GEMM for decode-sized MoE batches (0 = two stages)
 static int g_moe_bm = 0;       // nvl_set_tuning key 17: m-tile rows of the grouped MoE GEMMs (0 / 128: 128, 256)
 static int g_moe_gather = 1;   // nvl_set_tuning key 16: prefill MoE gathers the token rows into expert order before the grouped GEMM (0 = per-lane gather inside it)
 static int g_moe_small = 1;    // nvl_set_tuning key 8: fused MoE planning launch + combine folded into the next norm (0 = off)
@@ -1071,10 +1072,10 @@ void moe(nvl_model* m, const LayerW& l, int M) {
             NVL_HIP(hipGetLastError());
             a.A = m->moe_xg; a.a_rows = nullptr;
         }
-        a.w_expert_stride = (int64_t)2 * I * H; a.grp_bm = BM;
+        a.w_expert_stride = (int64_t)2 * I * H; a.grp_bm = BM; a.grp_deep = small && g_moe_deep;
         gemm(m, EPI_SWIGLU, false, a, 2.0 * pairs * 2 * I * H);
         GemmArgs d = mk(m->hbuf, I, l.t[NVL_T_MOE_OUT].p, m->moe_eo, H, nullptr, 1.f, max_mtiles, H, I);
-        d.tile_map = m->moe_tile_map; d.n_mtiles = m->moe_n_mtiles; d.w_expert_stride = (int64_t)H * I; d.grp_bm = BM;
+        d.tile_map = m->moe_tile_map; d.n_mtiles = m->moe_n_mtiles; d.w_expert_stride = (int64_t)H * I; d.grp_bm = BM; d.grp_deep = small && g_moe_deep;
         gemm(m, EPI_STORE, true, d, 2.0 * pairs * H * I);
     }
     if (small && !m->keep_hidden && m->pending_slices == 0 && H % 4 == 0 && H <= 1024 * NORM_ROW_MAXCH) {

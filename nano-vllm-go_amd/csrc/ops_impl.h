@@ -396,6 +396,7 @@ extern "C" int nvl_bench_gemm(int device, int M, int N, int K, int epi, int forc
 extern "C" int nvl_set_tuning(int key, int value) {
     if (key == 0) { const int old = g_force_tile; g_force_tile = value; return old; }
     if (key == 1) { const int old = g_sk_slices; g_sk_slices = value; return old; }
+    if (key == 19) { const int old = g_moe_deep; g_moe_deep = value; return old; }
     if (key == 18) { const int old = g_qkv_store_max_m; g_qkv_store_max_m = value; return old; }
     if (key == 17) { const int old = g_moe_bm; g_moe_bm = value; return old; }
     if (key == 16) { const int old = g_moe_gather; g_moe_gather = value; return old; }
