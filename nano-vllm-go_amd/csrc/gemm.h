@@ -554,6 +554,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmArgs p) {
 //     fused epilogue (bias / residual / SwiGLU / GELU) runs once per output element.  For SwiGLU
 //     NTW = 2: tile 0 is the gate block, tile 1 the up block of the same 16 features.
 // ------------------------------------------------------------------------------------------
+// weight fragments are read once per launch: non-temporal.  In the 64-row-group launches the groups of a weight block
+// read them side by side, so there they take the regular path and stay in L2 for the other groups.
+template <bool KEEP>
+__device__ __forceinline__ bf16x8 weight_load(const bf16x8* p) {
+    if constexpr (KEEP) return *p;
+    else return __builtin_nontemporal_load(p);
+}
+
 // m_passes > 1: block id -> (weight block, 64-row activation group).  Ids that differ by 8 share an XCD and are
 // dispatched back to back: the groups of one weight block stream the same weights at the same time.
 __device__ __forceinline__ void skinny_pass_remap(GemmArgs& p, int& bx) {
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     auto load_blk = [&](bf16x8 (&w)[U], bf16x8 (&x)[U][MT], int b) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            w[u] = __builtin_nontemporal_load((const bf16x8*)(wp + (int64_t)(b * U + u) * 512));
+            w[u] = weight_load<PASSES>((const bf16x8*)(wp + (int64_t)(b * U + u) * 512));
 #pragma unroll
             for (int i = 0; i < MT; i++) x[u][i] = *(const bf16x8*)(xp[i] + (int64_t)(b * U + u) * 512);
         }
@@ -633,7 +641,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     }
     if (b < nblk) comp_blk(wA, xA);
     for (int s = nblk * U; s < my_steps; s++) {      // ragged tail: fewer than U k-steps
-        const bf16x8 w = __builtin_nontemporal_load((const bf16x8*)(wp + (int64_t)s * 512));
+        const bf16x8 w = weight_load<PASSES>((const bf16x8*)(wp + (int64_t)s * 512));
 #pragma unroll
         for (int i = 0; i < MT; i++)
             acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, *(const bf16x8*)(xp[i] + (int64_t)s * 512), acc[i], 0, 0, 0);
@@ -806,7 +814,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
         for (int u = 0; u < U; u++) {
 #pragma unroll
             for (int t = 0; t < NTB; t++)
-                w[u][t] = __builtin_nontemporal_load((const bf16x8*)(wp + t * tile_stride + (int64_t)(b * U + u) * 512));
+                w[u][t] = weight_load<PASSES>((const bf16x8*)(wp + t * tile_stride + (int64_t)(b * U + u) * 512));
 #pragma unroll
             for (int i = 0; i < MT; i++) x[u][i] = *(const bf16x8*)(xp + i * tile_stride + (int64_t)(b * U + u) * 512);
         }
@@ -835,7 +843,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
         for (int i = 0; i < MT; i++) xs[i] = *(const bf16x8*)(xp + i * tile_stride + (int64_t)s * 512);
 #pragma unroll
         for (int t = 0; t < NTB; t++) {
-            const bf16x8 w = __builtin_nontemporal_load((const bf16x8*)(wp + t * tile_stride + (int64_t)s * 512));
+            const bf16x8 w = weight_load<PASSES>((const bf16x8*)(wp + t * tile_stride + (int64_t)s * 512));
 #pragma unroll
             for (int i = 0; i < MT; i++) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xs[i], acc[t][i], 0, 0, 0);
         }

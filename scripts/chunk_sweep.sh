@@ -1,6 +1,6 @@
-# bench.py at B x S under tuning overrides: "B S tune" (short generation: prefill-focused)
+# bench.py at "B S tune" points (decode-focused), one result line each
 rm -f gpurun_out/b_chunk_sweep.log
-for cfg in "1 128 18=64" "1 128 18=256" "1 256 18=64" "1 256 18=256" "1 512 18=64" "1 512 18=512" "4 128 18=64" "4 128 18=512"; do set -- $cfg; echo "B=$1 S=$2 $3" >> gpurun_out/b_chunk_sweep.log; timeout -k 10 200 python bench.py --no-cpu-baseline --prompt $2 --gen 8 --batch $1 --steps 5 --tune $3 2>&1 | python3 -c "
+for cfg in "128 128 20=0" "128 128 20=1" "128 128 20=2" "128 128 20=4" "256 128 20=0" "256 128 20=2"; do set -- $cfg; echo "B=$1 S=$2 $3" >> gpurun_out/b_chunk_sweep.log; timeout -k 10 200 python bench.py --no-cpu-baseline --prompt $2 --gen 128 --batch $1 --steps 2 --tune $3 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
