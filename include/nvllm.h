@@ -292,6 +292,8 @@ typedef struct nvl_stats {
     double   other_ms;                    /* norms, RoPE/KV write, activation, embedding, argmax      */
     uint64_t other_launches;
     double   weight_bytes;                /* bytes of weights resident on the device                  */
+    uint64_t evictions;                   /* KV slots reclaimed from the least-recently-forwarded sequence by
+                                             nvl_runner_run / _sampled when every slot was taken            */
 } nvl_stats;
 int nvl_set_profile(nvl_model* m, int per_kernel_events);
 int nvl_get_stats(nvl_model* m, nvl_stats* out);

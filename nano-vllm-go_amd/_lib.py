@@ -67,7 +67,8 @@ class StatsC(C.Structure):
                 ("prefill_ms", C.c_double), ("decode_ms", C.c_double),
                 ("gemm_ms", C.c_double), ("gemm_flops", C.c_double), ("gemm_launches", C.c_uint64),
                 ("attn_ms", C.c_double), ("attn_flops", C.c_double), ("attn_launches", C.c_uint64),
-                ("other_ms", C.c_double), ("other_launches", C.c_uint64), ("weight_bytes", C.c_double)]
+                ("other_ms", C.c_double), ("other_launches", C.c_uint64), ("weight_bytes", C.c_double),
+                ("evictions", C.c_uint64)]
 
 
 class SamplingParamsC(C.Structure):     # nvl_sampling_params == tensor.SamplingParams (sampling.go:10-15)

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 
 namespace nvl {
@@ -92,6 +93,24 @@ struct HipError {
     do {                                                                              \
         hipError_t _e = (expr);                                                       \
         if (_e != hipSuccess) throw ::nvl::HipError{_e, #expr, __FILE__, __LINE__};   \
+    } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (call site, DEVICE): a process may open model handles on
+// several devices (nvl_runtime_opts.device) and from several threads; a repeated set is harmless, a missing one is a
+// launch failure on the second device.
+struct LdsAttrOnce { std::atomic<uint32_t> done{0}; };
+static inline void ensure_lds_attr(LdsAttrOnce& g, const void* fn, int bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint32_t bit = 1u << (dev & 31);
+    if (g.done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    g.done.fetch_or(bit, std::memory_order_release);
+}
+#define NVL_LDS_ATTR(fn, bytes)                                        \
+    do {                                                               \
+        static ::nvl::LdsAttrOnce _once;                               \
+        ::nvl::ensure_lds_attr(_once, (const void*)(fn), (int)(bytes)); \
     } while (0)
 
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }

@@ -965,12 +965,7 @@ static inline bool launch_gemm_skinny_wide(hipStream_t st, const GemmArgs& a) {
     const int wgs = groups * (a.m_passes > 1 ? a.m_passes : 1);
 #define NVL_SKW(MTv, Uv, Pv)                                                                                             \
     do {                                                                                                               \
-        static bool attr = false;                                                                                      \
-        if (!attr) {                                                                                                   \
-            (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_bf16_kernel<MTv, NTB, Uv, EPI, OutT, Pv>,              \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 8 * NTB * MTv * 64 * 16);            \
-            attr = true;                                                                                               \
-        }                                                                                                              \
+        NVL_LDS_ATTR((gemm_skinny_wide_bf16_kernel<MTv, NTB, Uv, EPI, OutT, Pv>), 8 * NTB * MTv * 64 * 16);            \
         hipLaunchKernelGGL((gemm_skinny_wide_bf16_kernel<MTv, NTB, Uv, EPI, OutT, Pv>), dim3(wgs), dim3(ksplit * 64),      \
                            lds, st, a);                                                                                \
     } while (0)
@@ -996,12 +991,7 @@ static inline bool launch_gemm_skinny_bf16(hipStream_t st, const GemmArgs& a) {
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, typename OutT>
 static inline void launch_gemm_tile(hipStream_t st, const GemmArgs& a) {
     constexpr int lds = gemm_lds_bytes<BM, BN, STAGES>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, OutT>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    NVL_LDS_ATTR((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, OutT>), lds);
     const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, OutT>), dim3(tiles),
                        dim3(WAVES_M * WAVES_N * 64), lds, st, a);
@@ -1017,35 +1007,20 @@ template <int EPI, typename OutT>
 static inline void launch_gemm_grouped(hipStream_t st, const GemmArgs& a, int max_mtiles) {
     if (a.grp_bm == 256) {      // prefill MoE with long expert segments: 256-row m-tiles, three stages
         constexpr int lds3 = gemm_lds_bytes<256, 128, 3>();
-        static bool attr3 = false;
-        if (!attr3) {
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<256, 128, 4, 2, 3, EPI, OutT>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-            attr3 = true;
-        }
+        NVL_LDS_ATTR((gemm_bf16_kernel<256, 128, 4, 2, 3, EPI, OutT>), lds3);
         hipLaunchKernelGGL((gemm_bf16_kernel<256, 128, 4, 2, 3, EPI, OutT>), dim3(cdiv(a.N, 128) * max_mtiles), dim3(512),
                            lds3, st, a);
         return;
     }
     if (a.grp_deep) {           // decode MoE: a handful of rows per expert, one workgroup per CU streaming 128 weight rows —
         constexpr int lds4 = gemm_lds_bytes<128, 128, 4>();   // latency-bound with two stages (16 K tiles, one round trip each)
-        static bool attr4 = false;
-        if (!attr4) {
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<128, 128, 2, 2, 4, EPI, OutT>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
-            attr4 = true;
-        }
+        NVL_LDS_ATTR((gemm_bf16_kernel<128, 128, 2, 2, 4, EPI, OutT>), lds4);
         hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, 2, 4, EPI, OutT>), dim3(cdiv(a.N, 128) * max_mtiles), dim3(256),
                            lds4, st, a);
         return;
     }
     constexpr int lds = gemm_lds_bytes<128, 128, 2>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<128, 128, 2, 2, 2, EPI, OutT>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    NVL_LDS_ATTR((gemm_bf16_kernel<128, 128, 2, 2, 2, EPI, OutT>), lds);
     hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, 2, 2, EPI, OutT>), dim3(cdiv(a.N, 128) * max_mtiles), dim3(256),
                        lds, st, a);
 }
@@ -1075,12 +1050,7 @@ static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
         if (a.qkv.hd == 128) {     // a wave must own a whole 128-column head: 256x256 tile as 4x2 waves of 64x128
             const int t3 = cdiv(a.M, 256) * cdiv(a.N, 256);
             if (g_force_tile == 0 && t3 >= 192 && cu_fill(t3, 1) >= 0.74 && a.K >= 160 && !a.seg && !a.a_rows) {
-                static bool attr = false;     // the ping-pong form, wave tile 64x128
-                if (!attr) {
-                    (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI, OutT, 4, 0, 2>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 1024);
-                    attr = true;
-                }
+                NVL_LDS_ATTR((gemm_bf16_pp_kernel<EPI, OutT, 4, 0, 2>), 4 * 32 * 1024);     // the ping-pong form, wave tile 64x128
                 hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, OutT, 4, 0, 2>), dim3(t3), dim3(512), 4 * 32 * 1024, st, a);
                 return;
             }
@@ -1101,12 +1071,7 @@ static inline void launch_gemm_bf16(hipStream_t st, const GemmArgs& a) {
     }
 #define NVL_PP(TILE, ST, PR)                                                                                          \
     if (tile == TILE && !a.seg && !a.a_rows) {                                                                         \
-        static bool attr = false;                                                                                      \
-        if (!attr) {                                                                                                   \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI, OutT, ST, PR>,                             \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, ST * 32 * 1024);                     \
-            attr = true;                                                                                               \
-        }                                                                                                              \
+        NVL_LDS_ATTR((gemm_bf16_pp_kernel<EPI, OutT, ST, PR>), ST * 32 * 1024);                                        \
         hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, OutT, ST, PR>), dim3(cdiv(a.M, 256) * cdiv(a.N, 256)), dim3(512), \
                            ST * 32 * 1024, st, a);                                                                     \
         return;                                                                                                        \

@@ -43,12 +43,17 @@ struct JVal {
 
 struct JParser {
     const char* p; const char* end;
+    int depth = 0;                         // nesting is capped: a hostile header must not recurse the stack away
+    static constexpr int MAX_DEPTH = 64;
     JParser(const char* s, size_t n) : p(s), end(s + n) {}
     [[noreturn]] void bad(const char* what) { throw std::runtime_error(std::string("json: ") + what); }
     void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
     JVal parse() { ws(); JVal v = value(); ws(); return v; }
+    struct Depth { int& d; explicit Depth(int& d_) : d(d_) { ++d; } ~Depth() { --d; } };
     JVal value() {
         if (p >= end) bad("unexpected end");
+        Depth guard(depth);
+        if (depth > MAX_DEPTH) bad("nesting deeper than 64 levels");
         JVal v;
         switch (*p) {
             case '{': {
@@ -173,7 +178,17 @@ struct StSet {
             StTensor t;
             if (dt->str == "F32") t.dtype = NVL_DTYPE_F32; else if (dt->str == "BF16") t.dtype = NVL_DTYPE_BF16;
             else if (dt->str == "F16") t.dtype = NVL_DTYPE_F16; else t.dtype = -1;      // refused only if the model needs it (:660-662)
-            for (auto& d : sh->arr) { t.shape.push_back((int64_t)d.num); t.numel *= (int64_t)d.num; }
+            for (auto& d : sh->arr) {      // dimensions: non-negative integers whose product stays far inside int64
+                if (d.kind != JVal::NUM || !(d.num >= 0) || d.num > 4.0e12 || d.num != (double)(int64_t)d.num)
+                    throw std::runtime_error(path + ": bad dimension in the shape of " + kv.first);
+                const int64_t dim = (int64_t)d.num;
+                if (dim != 0 && t.numel > ((int64_t)1 << 46) / dim)
+                    throw std::runtime_error(path + ": shape of " + kv.first + " overflows");
+                t.shape.push_back(dim); t.numel *= dim;
+            }
+            if (off->arr[0].kind != JVal::NUM || off->arr[1].kind != JVal::NUM || !(off->arr[0].num >= 0) || !(off->arr[1].num >= 0) ||
+                off->arr[0].num > 9.0e15 || off->arr[1].num > 9.0e15)
+                throw std::runtime_error(path + ": bad data_offsets of " + kv.first);
             const size_t b = (size_t)off->arr[0].num, e = (size_t)off->arr[1].num;
             if (e < b || e > data_len) throw std::runtime_error(path + ": data_offsets of " + kv.first + " outside the file");
             t.data = data + b; t.bytes = e - b;
@@ -195,8 +210,13 @@ struct StSet {
             const JVal* wm = root.get("weight_map");
             if (!wm || wm->kind != JVal::OBJ) throw std::runtime_error(idx + ": no weight_map");
             std::vector<std::string> shards;
-            for (auto& kv : wm->obj)
-                if (std::find(shards.begin(), shards.end(), kv.second.str) == shards.end()) shards.push_back(kv.second.str);
+            for (auto& kv : wm->obj) {
+                const std::string& sn = kv.second.str;      // a shard is a plain file name inside the model directory
+                if (kv.second.kind != JVal::STR || sn.empty() || sn.find('/') != std::string::npos || sn.find('\\') != std::string::npos ||
+                    sn == "." || sn.find("..") != std::string::npos)
+                    throw std::runtime_error(idx + ": weight_map names a shard outside the model directory: '" + sn + "'");
+                if (std::find(shards.begin(), shards.end(), sn) == shards.end()) shards.push_back(sn);
+            }
             for (auto& s : shards) add_file(path + "/" + s);
             return;
         }

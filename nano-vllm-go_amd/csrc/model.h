@@ -49,6 +49,7 @@ struct nvl_local_group {
     std::mutex mu;
     std::condition_variable cv;
     int n = 0, arrived = 0, refs = 0;
+    bool aborted = false;        // a member failed: every waiter and every later all-reduce of the group errors out
     uint64_t gen = 0;
     float* bufs[8] = {nullptr};
     float* scratch = nullptr;
@@ -87,6 +88,9 @@ struct nvl_model {
     std::map<int64_t, int> seq_slot;
     std::vector<int> free_slots;
     std::vector<int> slot_len;
+    std::vector<uint64_t> slot_tick;   // last forward that touched the slot (LRU eviction in the runner entry points)
+    std::vector<char> slot_pin;        // 1 while the slot's sequence is part of the forward call being assembled
+    uint64_t tick = 0;
 
     // workspaces
     float* x = nullptr;          // residual stream fp32 [Mmax][H]

@@ -6,7 +6,9 @@
 // device and fails with NVL_ERR_NO_DEVICE / NVL_ERR_HIP otherwise.
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstring>
+#include <new>
 
 #include <rccl/rccl.h>
 
@@ -23,14 +25,27 @@ int fail(nvl_model* m, int code, const std::string& msg) {
     return code;
 }
 
+// a member of an in-process tensor-parallel group (nvl_tp_attach_local) that fails must not leave its peers waiting in
+// tp_allreduce forever: the failure poisons the group and wakes them
+void note_failure(nvl_model* m) {
+    if (!m || !m->tp_local) return;
+    { std::lock_guard<std::mutex> lk(m->tp_local->mu); m->tp_local->aborted = true; }
+    m->tp_local->cv.notify_all();
+}
+
 #define NVL_TRY(m) try {
 #define NVL_CATCH(m)                                                                     \
     } catch (const HipError& e) {                                                        \
+        note_failure(m);                                                                 \
         char buf[512];                                                                   \
         snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e.code,         \
                  hipGetErrorString(e.code), e.file, e.line, e.what);                     \
         return fail(m, e.code == hipErrorOutOfMemory ? NVL_ERR_OOM : NVL_ERR_HIP, buf);  \
+    } catch (const std::bad_alloc&) {                                                    \
+        note_failure(m);                                                                 \
+        return fail(m, NVL_ERR_OOM, "out of host memory");                               \
     } catch (const std::exception& e) {                                                  \
+        note_failure(m);                                                                 \
         return fail(m, NVL_ERR_INVALID, e.what());                                       \
     }
 
@@ -152,9 +167,6 @@ extern "C" const char* nvl_last_error(const nvl_model* m) { return m ? m->err.c_
 extern "C" int nvl_create(const nvl_model_config* cfg, const nvl_runtime_opts* opts, nvl_model** out) {
     if (!cfg || !opts || !out) return fail(nullptr, NVL_ERR_INVALID, "nvl_create: null argument");
     *out = nullptr;
-    if (nvl_device_count() <= opts->device)
-        return fail(nullptr, NVL_ERR_NO_DEVICE,
-                    "nvl_create: no HIP device (this library has no CPU fallback)");
     const nvl_model_config& c = *cfg;
     if (c.hidden <= 0 || c.num_layers <= 0 || c.num_heads <= 0 || c.head_dim <= 0 || c.vocab_size <= 0 ||
         c.max_seq_len <= 0)
@@ -163,6 +175,12 @@ extern "C" int nvl_create(const nvl_model_config* cfg, const nvl_runtime_opts* o
         return fail(nullptr, NVL_ERR_INVALID, "nvl_create: head_dim must be 64 or 128");
     if (c.hidden % 64 != 0 || (c.ffn_dim % 64) != 0)
         return fail(nullptr, NVL_ERR_INVALID, "nvl_create: hidden and ffn_dim must be multiples of 64");
+    // runtime options are validated BEFORE any size is derived from them (a zero-valued host struct must not turn into
+    // a 0-block KV cache): max_seqs >= 1 is required, max_batch_tokens 0 selects max_seq_len
+    if (opts->max_seqs <= 0)
+        return fail(nullptr, NVL_ERR_INVALID, "nvl_create: max_seqs must be >= 1 (KV slots / sequences per call)");
+    if (opts->max_batch_tokens < 0 || opts->kv_num_blocks < 0 || opts->kv_block_size < 0)
+        return fail(nullptr, NVL_ERR_INVALID, "nvl_create: negative max_batch_tokens / kv_num_blocks / kv_block_size");
     const int tp = opts->tp_size > 1 ? opts->tp_size : 1;
     if (tp > 1) {
         const int nkv_full = c.attention_type == NVL_ATTN_MHA ? c.num_heads : c.num_kv_heads;
@@ -173,7 +191,11 @@ extern "C" int nvl_create(const nvl_model_config* cfg, const nvl_runtime_opts* o
         if (c.num_heads % tp || nkv_full % tp || c.ffn_dim % (tp * 64))
             return fail(nullptr, NVL_ERR_INVALID, "nvl_create: heads, kv heads and ffn_dim/64 must divide by tp_size");
     }
-    nvl_model* m = new nvl_model();
+    if (opts->device < 0 || nvl_device_count() <= opts->device)
+        return fail(nullptr, NVL_ERR_NO_DEVICE,
+                    "nvl_create: no HIP device (this library has no CPU fallback)");
+    nvl_model* m = new (std::nothrow) nvl_model();
+    if (!m) return fail(nullptr, NVL_ERR_OOM, "nvl_create: out of host memory");
     NVL_TRY(m)
     m->cfg = c; m->opts = *opts;
     m->f32 = (opts->precision == NVL_PRECISION_F32);
@@ -212,7 +234,6 @@ extern "C" int nvl_create(const nvl_model_config* cfg, const nvl_runtime_opts* o
     else m->attn_scale = 1.0f / std::sqrt((float)m->hd);
     m->resid_alpha = c.residual_multiplier != 0.f ? c.residual_multiplier : 1.0f;
     m->layers.resize(m->L);
-    if (m->opts.max_seqs <= 0) m->opts.max_seqs = 1;
     if (m->opts.max_batch_tokens <= 0) m->opts.max_batch_tokens = c.max_seq_len;
     *out = m;
     return NVL_OK;
@@ -344,6 +365,17 @@ extern "C" int nvl_upload_tensor(nvl_model* m, int kind, int layer, const void* 
     if (is_1d(kind)) {
         const int64_t n = rows * (cols > 0 ? cols : 1);
         int64_t off = 0, cnt = n;
+        {   // the kernels read exactly this many elements: a short norm / bias tensor would be an out-of-bounds read
+            int64_t want = m->H;
+            if (kind == NVL_T_BQ) want = (int64_t)m->nH_full * m->hd;
+            else if (kind == NVL_T_BK || kind == NVL_T_BV) want = (int64_t)m->nKV_full * m->hd;
+            else if (kind == NVL_T_B1) want = m->F_full;
+            if (rows <= 0 || n != want) {
+                snprintf(buf, sizeof buf, "1-D tensor kind %d has %lld elements, the model needs %lld", kind, (long long)n,
+                         (long long)want);
+                return fail(m, NVL_ERR_INVALID, buf);
+            }
+        }
         if (m->tp > 1) {   // column-parallel biases follow their projection's shard; row-parallel biases stay on rank 0
             if (kind == NVL_T_BQ) { cnt = (int64_t)m->nH * m->hd; off = r * cnt; }
             else if (kind == NVL_T_BK || kind == NVL_T_BV) { cnt = (int64_t)m->nKV * m->hd; off = r * cnt; }
@@ -419,6 +451,7 @@ extern "C" int nvl_upload_tensor(nvl_model* m, int kind, int layer, const void* 
 // splitGPT2QKV (generic_loader.go:674-702): c_attn [H, 3H] is [in,out]; columns split Q|K|V.
 extern "C" int nvl_upload_gpt2_qkv(nvl_model* m, int layer, const float* w, const float* b) {
     if (!m || !w) return fail(m, NVL_ERR_INVALID, "nvl_upload_gpt2_qkv: null argument");
+    NVL_TRY(m)
     const int64_t H = m->H;
     std::vector<float> part((size_t)H * H);
     const int kinds[3] = {NVL_T_WQ, NVL_T_WK, NVL_T_WV};
@@ -434,12 +467,14 @@ extern "C" int nvl_upload_gpt2_qkv(nvl_model* m, int layer, const float* w, cons
         }
     }
     return NVL_OK;
+    NVL_CATCH(m)
 }
 
 // splitFalconQKV + combineMQAKV (generic_loader.go:705-765): rows of [H, (nH+2)*hd] hold
 // [Q_0 .. Q_{nH-1} | K | V] chunks of hd.
 extern "C" int nvl_upload_falcon_qkv(nvl_model* m, int layer, const float* qkv) {
     if (!m || !qkv) return fail(m, NVL_ERR_INVALID, "nvl_upload_falcon_qkv: null argument");
+    NVL_TRY(m)
     const int64_t H = m->H, nH = m->nH, hd = m->hd, roww = (nH + 2) * hd;
     std::vector<float> q((size_t)(H * nH * hd)), kv((size_t)(H * 2 * hd));
     for (int64_t r = 0; r < H; r++) {
@@ -449,6 +484,7 @@ extern "C" int nvl_upload_falcon_qkv(nvl_model* m, int layer, const float* qkv) 
     int rc = nvl_upload_tensor(m, NVL_T_WQ, layer, q.data(), NVL_DTYPE_F32, H, nH * hd, NVL_LAYOUT_IN_OUT);
     if (rc) return rc;
     return nvl_upload_tensor(m, NVL_T_WKV, layer, kv.data(), NVL_DTYPE_F32, H, 2 * hd, NVL_LAYOUT_IN_OUT);
+    NVL_CATCH(m)
 }
 
 namespace {
@@ -609,6 +645,8 @@ extern "C" int nvl_finalize(nvl_model* m) {
     NVL_HIP(hipMemsetAsync(m->kcache, 0, (size_t)kv_elems * m->wsize, m->stream));
     NVL_HIP(hipMemsetAsync(m->vcache, 0, (size_t)kv_elems * m->wsize, m->stream));
     m->slot_len.assign((size_t)m->opts.max_seqs, 0);
+    m->slot_tick.assign((size_t)m->opts.max_seqs, 0);
+    m->slot_pin.assign((size_t)m->opts.max_seqs, 0);
     m->free_slots.clear();
     for (int s = m->opts.max_seqs - 1; s >= 0; s--) m->free_slots.push_back(s);
 
@@ -713,14 +751,38 @@ extern "C" int nvl_tp_attach_local(nvl_model** models, int n) {
 // =================================================================================================
 // sequences
 // =================================================================================================
-extern "C" int nvl_seq_open(nvl_model* m, int64_t seq_id) {
+namespace {
+// Open a KV slot for seq_id.  evict: when every slot is taken, drop the least-recently-forwarded sequence that is not
+// pinned (= not part of the forward call being assembled) and reuse its slot.  The reference keeps map[int64]*KVCache
+// forever and the engine never calls ClearCache (tensor_model_runner.go:11-18,59-68; llm_engine.go:35-37), so the runner
+// entry points evict; a later decode of an evicted sequence finds no slot and is re-prefilled from its full TokenIDs
+// (runner_impl), which is what makes eviction safe.  The explicit nvl_seq_open keeps its NVL_ERR_NO_SLOT contract.
+int seq_open_impl(nvl_model* m, int64_t seq_id, bool evict) {
     if (!m || !m->finalized) return fail(m, NVL_ERR_STATE, "nvl_seq_open: model not finalized");
     if (m->paged) return fail(m, NVL_ERR_STATE, "nvl_seq_open: the model is in paged-KV mode (the host's block manager owns the cache)");
-    if (m->seq_slot.count(seq_id)) return NVL_OK;
-    if (m->free_slots.empty()) return fail(m, NVL_ERR_NO_SLOT, "nvl_seq_open: all KV slots in use");
+    auto it = m->seq_slot.find(seq_id);
+    if (it != m->seq_slot.end()) { m->slot_tick[(size_t)it->second] = ++m->tick; return NVL_OK; }
+    if (m->free_slots.empty()) {
+        if (!evict) return fail(m, NVL_ERR_NO_SLOT, "nvl_seq_open: all KV slots in use");
+        auto victim = m->seq_slot.end();
+        for (auto jt = m->seq_slot.begin(); jt != m->seq_slot.end(); ++jt) {
+            if (m->slot_pin[(size_t)jt->second]) continue;
+            if (victim == m->seq_slot.end() || m->slot_tick[(size_t)jt->second] < m->slot_tick[(size_t)victim->second]) victim = jt;
+        }
+        if (victim == m->seq_slot.end()) return fail(m, NVL_ERR_NO_SLOT, "nvl_runner_run: every KV slot belongs to the batch being assembled");
+        m->free_slots.push_back(victim->second);
+        m->seq_slot.erase(victim);
+        m->stats.evictions++;
+    }
     const int s = m->free_slots.back(); m->free_slots.pop_back();
-    m->seq_slot[seq_id] = s; m->slot_len[(size_t)s] = 0;
+    m->seq_slot[seq_id] = s; m->slot_len[(size_t)s] = 0; m->slot_tick[(size_t)s] = ++m->tick; m->slot_pin[(size_t)s] = 0;
     return NVL_OK;
+}
+}  // namespace
+extern "C" int nvl_seq_open(nvl_model* m, int64_t seq_id) {
+    NVL_TRY(m)
+    return seq_open_impl(m, seq_id, false);
+    NVL_CATCH(m)
 }
 extern "C" int nvl_seq_reset(nvl_model* m, int64_t seq_id) {
     const int rc = nvl_seq_open(m, seq_id);
@@ -788,12 +850,7 @@ void launch_norm(nvl_model* m, float* x, const int32_t* rows_idx, const float* w
         // 16 rows x H bf16 of LDS (up to 160 KiB); the row sits in registers: instance by chunks per lane
 #define NVL_NT16(CH)                                                                                                   \
         do {                                                                                                           \
-            static bool attr = false;                                                                                  \
-            if (!attr) {                                                                                               \
-                (void)hipFuncSetAttribute((const void*)norm_tile16_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                          160 * 1024);                                                                 \
-                attr = true;                                                                                           \
-            }                                                                                                          \
+            NVL_LDS_ATTR(norm_tile16_kernel<CH>, 160 * 1024);                                                          \
             hipLaunchKernelGGL(norm_tile16_kernel<CH>, dim3(cdiv(rows, 16)), dim3(1024), (size_t)16 * m->H * 2, m->stream, x, \
                                rows_idx, w, b, m->cfg.norm_eps, (bf16_t*)y, rows, m->H);                                \
         } while (0)
@@ -912,6 +969,7 @@ void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
     if (!g) throw std::runtime_error("tp_size > 1 but no communicator: call nvl_tp_init (RCCL) or nvl_tp_attach_local first");
     NVL_HIP(hipStreamSynchronize(m->stream));                 // this rank's partial is complete
     std::unique_lock<std::mutex> lk(g->mu);
+    if (g->aborted) throw std::runtime_error("tp local group: another member failed (group aborted)");
     if (count > g->scratch_floats) throw std::runtime_error("tp local group: scratch too small");
     g->bufs[m->tp_rank] = buf;
     const uint64_t my_gen = g->gen;
@@ -926,7 +984,14 @@ void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
         g->gen++;
         g->cv.notify_all();
     } else {
-        g->cv.wait(lk, [&] { return g->gen != my_gen; });
+        // a peer that fails sets `aborted` (note_failure); the timeout covers a peer that never calls at all
+        const bool ok = g->cv.wait_for(lk, std::chrono::seconds(120), [&] { return g->gen != my_gen || g->aborted; });
+        if (!ok || g->gen == my_gen) {
+            g->aborted = true;
+            g->cv.notify_all();
+            throw std::runtime_error(ok ? "tp local group: another member failed (group aborted)"
+                                        : "tp local group: timed out waiting for the other members");
+        }
     }
 }
 
@@ -1285,7 +1350,7 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
         const int slot = it->second;
         for (int j = 0; j < i; j++) if (seq_ids[j] == seq_ids[i]) return fail(m, NVL_ERR_INVALID, "nvl_forward: duplicate sequence in batch");
         if (pos_offsets[i] != m->slot_len[(size_t)slot]) return fail(m, NVL_ERR_INVALID, "nvl_forward: pos_offset does not equal the cached length");
-        if (pos_offsets[i] + seq_lens[i] > c.max_seq_len)   // rope.go:84-86 / :176-178 panic
+        if (pos_offsets[i] > c.max_seq_len - seq_lens[i])   // rope.go:84-86 / :176-178 panic
             return fail(m, NVL_ERR_POSITION, "nvl_forward: position exceeds max_seq_len");
         // slab mode: the sequence's block table is the one entry blk_table[i] = its slot
         h_sts[i] = t; h_len[i] = seq_lens[i]; h_pos[i] = pos_offsets[i]; h_slot[(size_t)i] = slot; h_tbl[i] = i; hm.blk_table[i] = slot;     // (blocks_per_seq == 1 here)
@@ -1319,7 +1384,7 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
         if (all) for (int i = 0; i < n_seqs; i++) argmax_out[i] = am[(size_t)h_last[i]];
         else for (int i = 0; i < n_seqs; i++) argmax_out[i] = am[(size_t)i];
     }
-    for (int i = 0; i < n_seqs; i++) m->slot_len[(size_t)h_slot[(size_t)i]] += seq_lens[i];
+    for (int i = 0; i < n_seqs; i++) { m->slot_len[(size_t)h_slot[(size_t)i]] += seq_lens[i]; m->slot_tick[(size_t)h_slot[(size_t)i]] = ++m->tick; }
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, m->ev0, m->ev1);
     m->stats.forward_calls++;
@@ -1356,9 +1421,12 @@ extern "C" int nvl_forward_paged(nvl_model* m, int n_seqs, const int32_t* tokens
     const int M = (int)M64;
     const Meta hm = bind_meta(m, m->meta_host, M);
     int t = 0, tb = 0;
+    if (table_offsets[0] < 0) return fail(m, NVL_ERR_INVALID, "nvl_forward_paged: negative table offset");
     for (int i = 0; i < n_seqs; i++) {
+        if (pos_offsets[i] > c.max_seq_len - seq_lens[i])      // (written so that the sum cannot overflow)
+            return fail(m, NVL_ERR_POSITION, "nvl_forward_paged: position exceeds max_seq_len");
         const int end = pos_offsets[i] + seq_lens[i];
-        if (end > c.max_seq_len) return fail(m, NVL_ERR_POSITION, "nvl_forward_paged: position exceeds max_seq_len");
+        if (table_offsets[i + 1] < table_offsets[i]) return fail(m, NVL_ERR_INVALID, "nvl_forward_paged: table_offsets must be non-decreasing");
         const int nb = table_offsets[i + 1] - table_offsets[i];
         if (nb < cdiv(end, BS)) return fail(m, NVL_ERR_INVALID, "nvl_forward_paged: block table shorter than the sequence");
         if (nb > m->blocks_per_seq) return fail(m, NVL_ERR_INVALID, "nvl_forward_paged: block table too long");
@@ -1418,6 +1486,7 @@ extern "C" int nvl_runner_run_paged(nvl_model* m, int n_seqs, const int32_t* con
     if (!m->paged) return fail(m, NVL_ERR_STATE, "nvl_runner_run_paged: the model was created without kv_num_blocks");
     if (n_seqs <= 0 || !token_ptrs || !token_lens || !block_table_ptrs || !block_table_lens || !next_tokens)
         return fail(m, NVL_ERR_INVALID, "nvl_runner_run_paged: null/empty arguments");
+    NVL_TRY(m)
     const int V = m->V;
     int k = 0;
     while (k < n_seqs) {
@@ -1459,6 +1528,7 @@ extern "C" int nvl_runner_run_paged(nvl_model* m, int n_seqs, const int32_t* con
         }
     }
     return NVL_OK;
+    NVL_CATCH(m)
 }
 
 namespace {
@@ -1559,7 +1629,7 @@ extern "C" int nvl_decode_greedy(nvl_model* m, int n_seqs, const int64_t* seq_id
         h_tokens[i] = first_tokens[i]; h_tok_pos[i] = pos; h_tok_tbl[i] = i;
     }
     decode_loop(m, hm, n_seqs, n_steps, out_tokens);
-    for (int i = 0; i < n_seqs; i++) m->slot_len[(size_t)h_slot[(size_t)i]] += n_steps;
+    for (int i = 0; i < n_seqs; i++) { m->slot_len[(size_t)h_slot[(size_t)i]] += n_steps; m->slot_tick[(size_t)h_slot[(size_t)i]] = ++m->tick; }
     return NVL_OK;
     NVL_CATCH(m)
 }
@@ -1582,9 +1652,12 @@ extern "C" int nvl_decode_greedy_paged(nvl_model* m, int n_seqs, const int32_t* 
     const int M = n_seqs, BS = m->Tmax;
     const Meta hm = bind_meta(m, m->meta_host, M);
     for (int i = 0; i < n_seqs; i++) {
-        const int pos = positions[i], end = pos + n_steps;
+        const int pos = positions[i];
         if (pos < 0) return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy_paged: negative position");
-        if (end > m->cfg.max_seq_len) return fail(m, NVL_ERR_POSITION, "nvl_decode_greedy_paged: position exceeds max_seq_len");
+        if (pos > m->cfg.max_seq_len - n_steps) return fail(m, NVL_ERR_POSITION, "nvl_decode_greedy_paged: position exceeds max_seq_len");
+        const int end = pos + n_steps;
+        if ((i == 0 && table_offsets[0] < 0) || table_offsets[i + 1] < table_offsets[i])
+            return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy_paged: table_offsets must be non-negative and non-decreasing");
         if (first_tokens[i] < 0 || first_tokens[i] >= m->V) return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy_paged: token id out of range");
         const int nb = table_offsets[i + 1] - table_offsets[i];
         if (nb < cdiv(end, BS) || nb > m->blocks_per_seq) return fail(m, NVL_ERR_INVALID, "nvl_decode_greedy_paged: block table does not cover the generated positions");
@@ -1674,7 +1747,7 @@ extern "C" int nvl_decode_sampled(nvl_model* m, int n_seqs, const int64_t* seq_i
     NVL_HIP(hipMemcpyAsync(m->samp_hist_len, hlen.data(), hlen.size() * 4, hipMemcpyHostToDevice, m->stream));
     NVL_HIP(hipMemcpyAsync(m->samp_u_steps, uniforms, (size_t)n_steps * n_seqs * 4, hipMemcpyHostToDevice, m->stream));
     decode_loop(m, hm, n_seqs, n_steps, out_tokens, params, m->samp_u_steps);   // (synchronises: the host vectors stay alive)
-    for (int i = 0; i < n_seqs; i++) m->slot_len[(size_t)h_slot[(size_t)i]] += n_steps;
+    for (int i = 0; i < n_seqs; i++) { m->slot_len[(size_t)h_slot[(size_t)i]] += n_steps; m->slot_tick[(size_t)h_slot[(size_t)i]] = ++m->tick; }
     return NVL_OK;
     NVL_CATCH(m)
 }
@@ -1874,18 +1947,33 @@ int runner_sample(nvl_model* m, const std::vector<int>& who, const int32_t* cons
     for (size_t j = 0; j < who.size(); j++) next_tokens[who[j]] = out[j];
     return NVL_OK;
 }
+// pins the slots of the sequences of the forward call being assembled, so that opening a slot for one of them never
+// evicts another (released on scope exit, also on errors)
+struct PinScope {
+    nvl_model* m; std::vector<int> slots;
+    explicit PinScope(nvl_model* m_) : m(m_) {}
+    void pin(int64_t seq_id) {
+        auto it = m->seq_slot.find(seq_id);
+        if (it != m->seq_slot.end() && !m->slot_pin[(size_t)it->second]) { m->slot_pin[(size_t)it->second] = 1; slots.push_back(it->second); }
+    }
+    ~PinScope() { for (int s : slots) m->slot_pin[(size_t)s] = 0; }
+};
 int runner_impl(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t* const* token_ptrs,
                 const int32_t* token_lens, int is_prefill, int32_t* next_tokens, float* logits_out,
                 const nvl_sampling_params* sp, const float* uniforms) {
     if (!m) return NVL_ERR_INVALID;
     if (!m->finalized) return fail(m, NVL_ERR_STATE, "nvl_runner_run: model not finalized");
+    if (m->paged) return fail(m, NVL_ERR_STATE, "nvl_runner_run: the model is in paged-KV mode (use nvl_runner_run_paged)");
     if (n_seqs <= 0 || !seq_ids || !token_ptrs || !token_lens || !next_tokens)
         return fail(m, NVL_ERR_INVALID, "nvl_runner_run: null/empty arguments");
-    // Partition: sequences that can take the 1-token decode path vs sequences that must be (re)prefilled.
+    NVL_TRY(m)      // (host containers below may throw bad_alloc: nothing may cross the C ABI)
+    // Partition: sequences that can take the 1-token decode path vs sequences that must be (re)prefilled: an unknown id
+    // (never seen, closed, or EVICTED since) or a cache whose length does not match is re-prefilled from the full history.
     std::vector<int> dec, pre;
     for (int i = 0; i < n_seqs; i++) {
-        if (token_lens[i] <= 0) return fail(m, NVL_ERR_INVALID, "nvl_runner_run: sequence without tokens");
+        if (!token_ptrs[i] || token_lens[i] <= 0) return fail(m, NVL_ERR_INVALID, "nvl_runner_run: sequence without tokens");
         if (token_lens[i] > m->cfg.max_seq_len) return fail(m, NVL_ERR_POSITION, "nvl_runner_run: sequence longer than max_seq_len");
+        for (int j = 0; j < i; j++) if (seq_ids[j] == seq_ids[i]) return fail(m, NVL_ERR_INVALID, "nvl_runner_run: duplicate sequence in batch");
         bool can_decode = false;
         if (!is_prefill) {
             auto it = m->seq_slot.find(seq_ids[i]);
@@ -1894,7 +1982,8 @@ int runner_impl(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t*
         (can_decode ? dec : pre).push_back(i);
     }
     const int V = m->V;
-    // ---- decode group: one token per sequence at position len-1 (:78-80)
+    // ---- decode group: one token per sequence at position len-1 (:78-80).  Runs before any slot is (re)opened below,
+    // so no decodable sequence of this batch can be evicted before its step.
     for (size_t base = 0; base < dec.size(); base += (size_t)m->opts.max_seqs) {
         const size_t n = std::min(dec.size() - base, (size_t)m->opts.max_seqs);
         std::vector<int64_t> ids(n); std::vector<int32_t> toks(n), lens(n, 1), pos(n), out(n);
@@ -1917,16 +2006,30 @@ int runner_impl(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t*
         }
     }
     // ---- prefill group: discard the cache, run the whole history from position 0 (:63-66,75);
-    // packed into forward calls of at most max_batch_tokens; a longer history is fed in chunks.
+    // packed into forward calls of at most max_batch_tokens; a longer history is fed in chunks.  A sequence without a
+    // slot takes a free one, or — the engine never calls ClearCache — the least-recently-forwarded slot outside the
+    // call being assembled (seq_open_impl).
+    auto reset_evict = [&](int64_t id) -> int {
+        const int rc = seq_open_impl(m, id, true);
+        if (rc) return rc;
+        m->slot_len[(size_t)m->seq_slot[id]] = 0;
+        return NVL_OK;
+    };
+    for (int i : pre) {      // this call's own sequences are the most recently used: victims come from outside the batch first
+        auto it = m->seq_slot.find(seq_ids[i]);
+        if (it != m->seq_slot.end()) m->slot_tick[(size_t)it->second] = ++m->tick;
+    }
     size_t k = 0;
     while (k < pre.size()) {
         std::vector<int64_t> ids; std::vector<int32_t> toks, lens, pos; std::vector<int> who;
         int64_t budget = m->opts.max_batch_tokens;
+        PinScope pins(m);
         while (k < pre.size() && (int)ids.size() < m->opts.max_seqs) {
             const int i = pre[k];
             if (token_lens[i] > budget) break;
-            int rc = nvl_seq_reset(m, seq_ids[i]);
+            int rc = reset_evict(seq_ids[i]);
             if (rc) return rc;
+            pins.pin(seq_ids[i]);
             ids.push_back(seq_ids[i]); lens.push_back(token_lens[i]); pos.push_back(0); who.push_back(i);
             toks.insert(toks.end(), token_ptrs[i], token_ptrs[i] + token_lens[i]);
             budget -= token_lens[i];
@@ -1934,7 +2037,7 @@ int runner_impl(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t*
         }
         if (ids.empty()) {   // one history longer than max_batch_tokens: chunked prefill of that sequence
             const int i = pre[k];
-            int rc = nvl_seq_reset(m, seq_ids[i]);
+            int rc = reset_evict(seq_ids[i]);
             if (rc) return rc;
             int done = 0; int32_t out = 0;
             std::vector<float> lg(logits_out ? (size_t)V : 0);
@@ -1969,6 +2072,7 @@ int runner_impl(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t*
         }
     }
     return NVL_OK;
+    NVL_CATCH(m)
 }
 }  // namespace
 

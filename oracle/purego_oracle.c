@@ -29,9 +29,22 @@ static float* fzeros(int64_t n) {
 /* ops: purego/tensor/tensor.go                                              */
 /* ------------------------------------------------------------------------ */
 
+/* Test-time knobs (NOT part of the restated algorithm).
+ * po_set_threads(n): rows i of MatMul are independent in the reference's i-p-j loop, so computing different rows on
+ *   different threads leaves every output element's arithmetic (p ascending, fp32, unfused) bit-identical; the
+ *   reference itself is single-threaded, and the cpu_baseline leg of bench.py keeps n = 1.
+ * po_set_lm_head_last_only(1): ForwardWithCache's LM head (generic_model.go:469) runs on the last row only — the row
+ *   GetLogitsForLastToken (generic_model.go:595-604) returns; logits_out is then [1, V].  Rows are independent, so the
+ *   returned row is bit-identical to the all-rows computation; it only skips work whose result the caller drops. */
+static int g_threads = 1;
+static int g_last_only = 0;
+void po_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+void po_set_lm_head_last_only(int on) { g_last_only = on != 0; }
+
 /* MatMul, tensor.go:62-88: i-p-j loop, C zero-initialised, C += a*b in fp32. */
 void po_matmul(const float* a, const float* b, float* c, int m, int k, int n) {
     memset(c, 0, (size_t)m * (size_t)n * sizeof(float));
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1 && m > 1)
     for (int i = 0; i < m; i++) {
         const float* arow = a + (int64_t)i * k;
         float* crow = c + (int64_t)i * n;
@@ -798,9 +811,10 @@ int po_forward_with_cache(po_model* m, const int32_t* tokens, int n_tokens,
     /* final norm + LM head on ALL rows, generic_model.go:464-477 */
     po_layernorm(x, m->global[PO_T_FINAL_NORM_W].p, m->global[PO_T_FINAL_NORM_B].p, c->norm_eps,
                  normed, S, H);
-    po_matmul(normed, m->global[PO_T_LM_HEAD].p, logits_out, S, H, V);
+    const int lrows = g_last_only ? 1 : S;      /* test-time knob, see po_set_lm_head_last_only */
+    po_matmul(normed + (int64_t)(S - lrows) * H, m->global[PO_T_LM_HEAD].p, logits_out, lrows, H, V);
     if (c->logits_scaling != 0.0f)
-        for (int64_t j = 0; j < (int64_t)S * V; j++) logits_out[j] = logits_out[j] / c->logits_scaling;
+        for (int64_t j = 0; j < (int64_t)lrows * V; j++) logits_out[j] = logits_out[j] / c->logits_scaling;
 
     free(x); free(normed);
     return err;

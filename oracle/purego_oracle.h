@@ -101,6 +101,11 @@ int po_forward_with_cache(po_model* m, const int32_t* tokens, int n_tokens,
                           po_kvcache* kv, int pos_offset,
                           float* logits_out, float* hidden_out);
 
+/* test-time knobs, not part of the restated algorithm (see purego_oracle.c): row-parallel MatMul (bit-identical per
+ * row; default 1 thread like the reference) and "LM head on the last row only" (logits_out becomes [1, V]) */
+void po_set_threads(int n);
+void po_set_lm_head_last_only(int on);
+
 /* cmd/ask/main.go:389-402 */
 int po_argmax(const float* data, int n);
 

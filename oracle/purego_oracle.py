@@ -76,6 +76,8 @@ def lib():
         L.po_forward_with_cache.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_void_p]
         L.po_argmax.argtypes = [C.c_void_p, C.c_int]
+        L.po_set_threads.argtypes = [C.c_int]
+        L.po_set_lm_head_last_only.argtypes = [C.c_int]
         L.po_sample_with_history.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int,
                                              C.c_float, C.c_float, C.c_void_p]
         L.po_matmul.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3
@@ -175,12 +177,18 @@ class OracleModel:
     def new_cache(self) -> KVCache:
         return KVCache(self.cfg["num_layers"])
 
-    def forward_with_cache(self, tokens, kv: KVCache, pos_offset: int, want_hidden: bool = False):
+    def forward_with_cache(self, tokens, kv: KVCache, pos_offset: int, want_hidden: bool = False,
+                           last_only: bool = False):
+        """last_only: the LM head runs on the last row only (test-time knob; the returned row is bit-identical)."""
         toks = np.ascontiguousarray(tokens, dtype=np.int32)
         S = toks.size
-        logits = np.empty((S, self.cfg["vocab_size"]), np.float32)
+        logits = np.empty((1 if last_only else S, self.cfg["vocab_size"]), np.float32)
         hidden = np.empty((self.cfg["num_layers"], S, self.cfg["hidden"]), np.float32) if want_hidden else None
-        rc = lib().po_forward_with_cache(self.h, _p(toks), S, kv.h, int(pos_offset), _p(logits), _p(hidden))
+        lib().po_set_lm_head_last_only(1 if last_only else 0)
+        try:
+            rc = lib().po_forward_with_cache(self.h, _p(toks), S, kv.h, int(pos_offset), _p(logits), _p(hidden))
+        finally:
+            lib().po_set_lm_head_last_only(0)
         if rc != 0:
             raise RuntimeError("oracle: the reference panics on this input (position or token out of range)")
         return (logits, hidden) if want_hidden else logits
@@ -212,6 +220,11 @@ class OracleModel:
 
 
 # ---- op-level wrappers --------------------------------------------------------------------
+def set_threads(n: int):
+    """Row-parallel MatMul in the oracle (bit-identical per row; the reference and the cpu_baseline use 1)."""
+    lib().po_set_threads(int(n))
+
+
 def argmax(x) -> int:
     a = _f32(x)
     return int(lib().po_argmax(_p(a), a.size))

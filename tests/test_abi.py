@@ -28,7 +28,7 @@ def test_struct_mirrors_match_the_header(pkg):
     lib = pkg.lib()
     assert C.sizeof(L.ModelConfigC) == lib.nvl_sizeof(0) == 104     # 13 x i32, pad, f64, f32, i32, 3 x i32, 4 x f32, pad
     assert C.sizeof(L.RuntimeOptsC) == lib.nvl_sizeof(1) == 40
-    assert C.sizeof(L.StatsC) == lib.nvl_sizeof(2) == 14 * 8
+    assert C.sizeof(L.StatsC) == lib.nvl_sizeof(2) == 15 * 8
     assert C.sizeof(L.SamplingParamsC) == lib.nvl_sizeof(3) == 16
     assert [n for n, _ in L.ModelConfigC._fields_][:3] == ["vocab_size", "hidden", "num_layers"]
     assert len(L.SLOTS) == 25 and L.SLOT_ID["moe_out"] == 24      # NVL_T_COUNT
@@ -54,3 +54,19 @@ def test_product_package_never_imports_the_oracle(pkg):
     for p in list(root.rglob("*.py")) + list(root.rglob("*.h")) + list(root.rglob("*.hip")) + list(root.rglob("Makefile")):
         text = p.read_text()
         assert "purego_oracle" not in text and "import oracle" not in text and "from oracle" not in text, p
+
+
+def test_create_validates_options_before_touching_a_device(pkg):
+    """A zero-valued host options struct (max_seqs = 0) must be refused, not turned into a 0-block KV cache
+    (the check runs before the device probe, so it is testable without a GPU)."""
+    import ctypes as C
+    L = pkg._lib
+    lib = pkg.lib()
+    from importlib import import_module
+    cfgc = import_module("nano-vllm-go_amd.model")._cfg_struct(pkg.synth.tiny_config("llama"))
+    h = C.c_void_p()
+    for bad in (dict(max_seqs=0), dict(max_seqs=-3), dict(max_seqs=2, max_batch_tokens=-1), dict(max_seqs=2, kv_num_blocks=-1)):
+        opts = L.RuntimeOptsC(device=0, precision=0, tp_size=1, **bad)
+        assert lib.nvl_create(C.byref(cfgc), C.byref(opts), C.byref(h)) == -1, bad     # NVL_ERR_INVALID
+        assert not h.value
+        assert b"nvl_create" in lib.nvl_last_error(None)

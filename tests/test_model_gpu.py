@@ -153,6 +153,52 @@ def test_runner_semantics(gpu, oracle):
     hm.close()
 
 
+def test_runner_evicts_lru_when_slots_run_out(gpu, oracle):
+    """The reference keeps map[int64]*KVCache forever and the engine never calls ClearCache
+    (tensor_model_runner.go:11-18,59-68; llm_engine.go:35-37).  With max_seqs = 4 KV slots, 12 distinct seq_ids go
+    through nvl_runner_run with NO ClearCache, decodes interleaved: the runner evicts the least-recently-forwarded
+    sequence, an evicted live sequence is transparently re-prefilled, every token equals the oracle's greedy id."""
+    cfg, om, hm = build(gpu, oracle, "llama", "f32", peaked=4.0, tied_embedding=False)     # max_seqs = 4
+    runner = gpu.HipModelRunner(hm)
+    r = np.random.default_rng(16)
+    seqs = [gpu.Sequence(seq_id=1000 + 7 * i, token_ids=r.integers(0, cfg["vocab_size"], int(n)).tolist())
+            for i, n in enumerate(r.integers(2, 12, 12))]
+    n_new = 4
+    want = [om.greedy(s.token_ids, n_new) for s in seqs]
+    got = [[] for _ in seqs]
+    # waves of 3 sequences (< max_seqs, so older ones survive for a while), each wave: prefill then one decode step;
+    # later rounds come back to EVERY sequence, oldest first, for further decode steps -> most of them were evicted
+    for w0 in range(0, 12, 3):
+        wave = list(range(w0, w0 + 3))
+        toks = runner.run([seqs[i] for i in wave], True)
+        for i, t in zip(wave, toks):
+            got[i].append(t); seqs[i].append_token(t)
+        toks = runner.run([seqs[i] for i in wave], False)
+        for i, t in zip(wave, toks):
+            got[i].append(t); seqs[i].append_token(t)
+    assert hm.stats()["evictions"] >= 8
+    for _ in range(n_new - 2):
+        for w0 in range(0, 12, 4):           # batches of 4 = max_seqs: every slot is pinned by the batch itself
+            wave = list(range(w0, w0 + 4))
+            toks = runner.run([seqs[i] for i in wave], False)
+            for i, t in zip(wave, toks):
+                got[i].append(t); seqs[i].append_token(t)
+    assert got == want
+    # a batch larger than the slot pool is served in max_seqs-sized forward calls (and thrashes, but stays correct)
+    toks = runner.run(seqs, False)
+    for i, s in enumerate(seqs):
+        ref = om.forward_with_cache(s.token_ids, om.new_cache(), 0)[-1]
+        assert toks[i] == oracle.argmax(ref)
+    # the explicit slot API keeps its contract: no silent eviction
+    hm.seq_close_all()
+    for sid in range(4):
+        gpu._lib.check(hm.lib.nvl_seq_open(hm.h, 5000 + sid), hm.h)
+    with pytest.raises(gpu.NvlError) as e:
+        gpu._lib.check(hm.lib.nvl_seq_open(hm.h, 5004), hm.h)
+    assert e.value.code == -4                                       # NVL_ERR_NO_SLOT
+    hm.close()
+
+
 def test_errors_instead_of_panics(gpu, oracle):
     cfg, om, hm = build(gpu, oracle, "llama", "f32", max_seq_len=64)
     hm.seq_reset(1)

@@ -151,3 +151,26 @@ def test_sample_with_history_known_answers(oracle):
     _, p0 = oracle.sample_with_history(logits, None, 0.5, temperature=0.0, repetition_penalty=1.0, return_probs=True)
     e = np.exp(logits.astype(np.float64) - 2.0)
     assert np.allclose(p0, e / e.sum(), atol=1e-6)
+
+
+def test_test_time_knobs_do_not_change_a_bit(oracle, pkg):
+    """po_set_threads (row-parallel MatMul) and last_only (LM head on the last row) are test-time accelerators of the
+    oracle: every value they return is bit-identical to the single-threaded all-rows computation."""
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((37, 96)).astype(np.float32)
+    b = rng.standard_normal((96, 130)).astype(np.float32)
+    one = oracle.matmul(a, b)
+    oracle.set_threads(4)
+    try:
+        four = oracle.matmul(a, b)
+        cfg = pkg.synth.tiny_config("llama")
+        w = pkg.synth.make_weights(cfg, seed=2, scale=0.05)
+        om = oracle.OracleModel(cfg, w)
+        toks = rng.integers(0, cfg["vocab_size"], 19).tolist()
+        thr = om.forward_with_cache(toks, om.new_cache(), 0)
+        last = om.forward_with_cache(toks, om.new_cache(), 0, last_only=True)
+    finally:
+        oracle.set_threads(1)
+    ref = om.forward_with_cache(toks, om.new_cache(), 0)
+    assert np.array_equal(one, four)
+    assert np.array_equal(thr, ref) and last.shape == (1, cfg["vocab_size"]) and np.array_equal(last[0], ref[-1])
