@@ -9,7 +9,8 @@ every token the path processed (B*S + B*G) per second, summed over ranks (data p
 sequences: each rank owns its own sequences and KV slabs, no collective on the data path).
 
   python bench.py --gpus 1 --steps 3 --warmup 1
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N ...            (starts its own N rank processes, one per GPU, before any GPU call)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (ranks given by the launcher)
 
 Inputs are resident in HBM before the timed region (weights uploaded, token ids are 4 bytes each).
 """
@@ -56,6 +57,9 @@ def parse():
                     help="control-flow rehearsal of the multi-rank path on a box with ONE GPU: every rank uses device 0 and "
                          "the rendezvous/barrier/max-reduce run over gloo (the printed value is meaningless)")
     ap.add_argument("--tune", default="", help="nvl_set_tuning overrides, e.g. 1=2 (key=value, comma separated)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="no GPU work: every rank joins the rendezvous (gloo), passes the barrier / max-reduce and rank 0 "
+                         "prints a line with n_gpus — the multi-rank control flow on a CPU-only machine")
     return ap.parse_args()
 
 
@@ -145,27 +149,37 @@ def flops_per_token(cfg):
 
 def main():
     args = parse()
+    pkg = importlib.import_module("nano-vllm-go_amd")        # (ctypes declarations only: no HIP call yet)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly with --gpus N: become the launcher.  N fresh rank processes (one per GPU) are started BEFORE
+        # this process makes any GPU call; it never turns into a rank and never execs.
+        sys.exit(pkg.dist.launch_local_ranks([str(Path(__file__).resolve()), *sys.argv[1:]], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch  # plumbing: device RNG for the synthetic weights, barrier/max-reduce across ranks
     import torch.distributed as dist
 
-    pkg = importlib.import_module("nano-vllm-go_amd")
+    if args.launch_check:
+        if world > 1:
+            pkg.dist.init("gloo")
+            dist.barrier()
+        t = pkg.dist.max_over_ranks([float(rank + 1)])
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "max_rank_plus_1": t[0]}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if args.rehearse_on_one_gpu:
         local_rank = 0
     assert pkg.lib().nvl_device_count() > local_rank, "bench.py needs a GPU: the HIP path has no CPU fallback"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=device)
+        pkg.dist.init("gloo" if args.rehearse_on_one_gpu else "nccl", None if args.rehearse_on_one_gpu else device)
 
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
@@ -241,11 +255,8 @@ def main():
         dec_s += d
     sync_all()
     elapsed = time.perf_counter() - t_start
-    times = torch.tensor([elapsed, pre_s, dec_s], dtype=torch.float64,
-                         device="cpu" if args.rehearse_on_one_gpu else device)
-    if world > 1:
-        dist.all_reduce(times, op=dist.ReduceOp.MAX)
-    elapsed, pre_s, dec_s = [float(x) for x in times.cpu()]
+    elapsed, pre_s, dec_s = pkg.dist.max_over_ranks([elapsed, pre_s, dec_s],
+                                                    device="cpu" if args.rehearse_on_one_gpu else device)
     st = model.stats()
 
     tokens_per_step = B * S + B * G

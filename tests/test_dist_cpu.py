@@ -57,3 +57,34 @@ def test_dp_over_sequences_world2_gloo(pkg, oracle):
     assert sorted(mine0 + mine1) == [0, 1, 2, 3, 4] and not set(mine0) & set(mine1)
     assert all0 == want and all1 == want           # every rank sees the whole batch's tokens, in batch order
     assert t0 == t1 == [2.0, 0.5]                  # max over ranks
+
+
+def _bench(*args, timeout=180):
+    import json
+    import subprocess
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True, timeout=timeout,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, [json.loads(ln) for ln in lines], p.stderr
+
+
+def test_bench_started_plainly_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no external launcher (what the driver runs) must itself start N rank processes:
+    the control flow (spawn before any GPU call, rendezvous, barrier, max over ranks, ONE line from rank 0) on CPU."""
+    rc, lines, err = _bench("--gpus", "2", "--launch-check")
+    assert rc == 0, err
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["max_rank_plus_1"] == 2.0
+    rc, lines, err = _bench("--gpus", "1", "--launch-check")
+    assert rc == 0 and lines[0]["n_gpus"] == 1
+
+
+def test_launcher_propagates_a_failing_rank(pkg, tmp_path):
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\nr = int(os.environ['RANK'])\n"
+                      "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                      "if r == 1: sys.exit(7)\ntime.sleep(30)\n")
+    import time
+    t0 = time.monotonic()
+    rc = pkg.dist.launch_local_ranks([str(script)], 3)
+    assert rc == 7 or rc == 15          # rank 1's code; the sleeping ranks were terminated, not waited for
+    assert time.monotonic() - t0 < 20

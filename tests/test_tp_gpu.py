@@ -106,3 +106,60 @@ def test_rccl_single_rank_communicator(gpu):
     assert rel_err(b2, a2) <= 1.5e-2
     ref.close()
     one.close()
+
+
+def test_tp8_llama3_8b_shapes_match_unsharded_oracle(gpu, oracle):
+    """BASELINE config 5, "Llama-3-8B bf16 TP=8": the T = 8 slice at the real widths — hd 128, exactly ONE KV head and
+    4 query heads per rank, F/8 = 1792 = 28 x 64 SwiGLU columns (an odd count of 128-wide tiles), V = 128256 — as 8
+    shard models of a 1-layer model in one process (nvl_tp_attach_local; one GPU per box).  Prefill of 320 tokens
+    (fused hd-128 QKV epilogue, tile kernels on the sharded widths) + 3 decode steps; every rank's logits equal the
+    UN-SHARDED CPU oracle's within the bf16 tolerance and are bit-identical across ranks."""
+    tp = 8
+    cfg = dict(gpu.synth.FULL_CONFIGS["llama-3-8b"], num_layers=1)
+    assert cfg["head_dim"] == 128 and cfg["num_kv_heads"] // tp == 1 and cfg["ffn_dim"] // tp == 1792
+    w = gpu.synth.make_weights(cfg, seed=21, scale=0.02)
+    om = oracle.OracleModel(cfg, w)
+    shards = [gpu.HipTransformerModel(cfg, w, precision="bf16", max_seqs=2, max_batch_tokens=512, tp_rank=r, tp_size=tp)
+              for r in range(tp)]
+    gpu.HipTransformerModel.attach_local_group(shards)
+    r = np.random.default_rng(12)
+    prompt = r.integers(0, cfg["vocab_size"], 320).tolist()
+    oracle.set_threads(min(16, __import__("os").cpu_count() or 1))     # row-parallel MatMul: bit-identical, just faster
+    try:
+        kv = om.new_cache()
+        want = om.forward_with_cache(prompt, kv, 0, last_only=True)[-1]
+        got = run_group(shards, lambda m: m.forward_with_cache(prompt, seq_id=1, pos_offset=0, all_logits=False)[-1])
+        for g in got:
+            assert rel_err(g, want) <= TOL["bf16"]
+            assert np.array_equal(g, got[0])
+        pos = len(prompt)
+        tok = oracle.argmax(want)
+        for _ in range(3):
+            want = om.forward_with_cache([tok], kv, pos)[-1]
+            got = run_group(shards, lambda m: m.forward_with_cache([tok], seq_id=1, pos_offset=pos, all_logits=False)[-1])
+            for g in got:
+                assert rel_err(g, want) <= TOL["bf16"]
+                assert np.array_equal(g, got[0])
+            tok = oracle.argmax(want)
+            pos += 1
+    finally:
+        oracle.set_threads(1)
+        for m in shards:
+            m.close()
+
+
+def test_bench_launches_two_ranks_on_one_gpu(gpu):
+    """`python bench.py --gpus 2` started plainly (no torchrun) must itself start 2 ranks and report n_gpus = 2: the
+    data-parallel path end to end with both ranks on this box's one device (--rehearse-on-one-gpu: rendezvous /
+    barrier / max-reduce over gloo; the value is meaningless, the control flow is what is checked)."""
+    import json, os, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--batch", "2",
+                        "--prompt", "64", "--gen", "4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0
+    assert lines[0]["config"]["parallelism"].startswith("dp2")
