@@ -13,8 +13,9 @@
 //     O^T[d,  q] += V^T[d, key] · P^T[key, q]      (A = V^T tile rows, B = P^T straight from the
 //                                                   S^T accumulators — no LDS, no shuffles)
 // so the softmax row (fixed q) lives on one lane column: the max/sum need two xor-shuffles, and the
-// O rescale is lane-local.  The V cache is kept TRANSPOSED in HBM ([hd][T]) so the V^T tile is a
-// coalesced load and its fragments are 8-byte LDS reads.
+// O rescale is lane-local.  K and V are both kept ROW-MAJOR in HBM ([T][hd], the reference's own cache
+// layout, kv_cache.go:5-6): appends are contiguous rows, the prefill kernel gets the V^T operand from
+// its LDS image with transposed reads (ds_read_b64_tr_b16), the decode kernel reads V as whole rows.
 //
 // f32 kernel (parity mode): one workgroup per (query position, head); scores in LDS; plain fp32.
 #pragma once
@@ -28,7 +29,7 @@ struct AttnArgs {
     void* out;            // [tokens][out_stride] (bf16: fragment-major, fp32: row-major); head h at column h*HD
     int out_stride;
     const void* kcache;   // layer base; (block, kvh) at block*slot_stride + kvh*Tmax*HD; [Tmax][HD]
-    const void* vcache;   // bf16: V^T [HD][Tmax]; f32: [Tmax][HD]
+    const void* vcache;   // same layout as kcache: [Tmax][HD]
     int64_t slot_stride;  // elements between consecutive KV blocks
     int Tmax;             // tokens per KV block (a multiple of 64): the whole slot in slab mode, 256 in paged mode
     const int32_t* seq_tok_start;
@@ -51,17 +52,42 @@ struct AttnArgs {
 // index of the KV block that holds key `key`
 __device__ __forceinline__ int kv_block_index(const AttnArgs& p, int key) { return p.bs_shift >= 0 ? (key >> p.bs_shift) : key / p.Tmax; }
 
-template <int HD, int TQ>
-__global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
-    // TQ = 16-row query sub-tiles per wave: every K / V^T fragment read from LDS feeds TQ MFMAs (the loop is LDS-bound at
-    // TQ = 1: 1 KiB of fragment reads per MFMA).  A workgroup covers 64 * TQ query rows.
-    constexpr int KROW = HD + 8;       // bf16 elements per K tile row (padded: 144 B for HD=64)
-    constexpr int VROW = 64 + 8;       // bf16 elements per V^T tile row
-    constexpr int KS = HD / 32;        // k-steps of the QK^T product
-    constexpr int DT = HD / 16;        // 16-row d tiles of O^T
-    constexpr int QROWS = 64 * TQ;     // query rows per workgroup
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * KROW];
-    __shared__ __attribute__((aligned(16))) bf16_t Vts[HD * VROW];
+// ------------------------------------------------------------------------------------------
+// LDS image of one 64-key K or V tile ([64 keys][HD] bf16, rows of CPR = HD/8 16-byte chunks).  The tile arrives by
+// LDS-DMA (global_load_lds_dwordx4: lane l of a 1-KiB piece lands at byte 16*l of the piece), so the image is a
+// permutation of 16-byte chunks chosen through the SOURCE address: chunk c of row r sits at chunk position
+//     r * CPR + (((c >> 1) ^ swz(r)) << 1 | (c & 1)),      swz(r) = (r >> 1) & 3 (HD 64),  r & 7 (HD 128)
+// i.e. the 32-byte column segments of a row are XOR-ed with a row-dependent pattern.  With it both read patterns are
+// bank-conflict-free: the K fragment ds_read_b128s (16 rows x the same chunk per 16-lane group) and the V
+// ds_read_b64_tr_b16 transposed reads (8 consecutive rows x one 32-byte segment per half wave).
+// ------------------------------------------------------------------------------------------
+template <int HD> __device__ __forceinline__ int kv_swz(int row) { return HD == 64 ? ((row >> 1) & 3) : (row & 7); }
+template <int HD> __device__ __forceinline__ int kv_img_chunk(int row, int c) {     // chunk position inside the image
+    return row * (HD / 8) + ((((c >> 1) ^ kv_swz<HD>(row)) << 1) | (c & 1));
+}
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x4 lds_read_tr4(const char* addr) {
+    // ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements, delivered column-major
+    // (lane i gets column i of the 4 rows).  EXEC must be all ones.
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(addr));
+    return __builtin_bit_cast(bf16x4, v);
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 prefill kernel.  One workgroup = 8 waves = 256 query rows of one (sequence, kv head); each wave owns 32 rows as
+// two 16-row sub-tiles, so every K / V fragment read from LDS feeds two MFMAs.  K and V tiles (64 keys) stream
+// HBM -> LDS by LDS-DMA through a 3-slot ring, two tiles ahead of the compute, with ONE barrier per tile:
+//     wait (my pieces of tile kt landed)  |  barrier  |  issue tile kt+2 into the slot tile kt-1 used  |  compute tile kt
+// (a slot is re-filled only after every wave passed the barrier that follows its last read; LDS-DMA is ordered by the
+// issuing wave's vmcnt + that barrier).  Two waves per SIMD: one wave's softmax VALU runs beside the other's MFMAs.
+// ------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(512, HD == 64 ? 4 : 2) void attn_prefill_bf16_kernel(AttnArgs p) {
+    constexpr int KS = HD / 32, DT = HD / 16, CPR = HD / 8, TQ = 2;
+    constexpr int TILE_BYTES = 64 * HD * 2, PIECES = TILE_BYTES / 1024, PW = 2 * PIECES / 8, NBUF = 3;
+    constexpr int QROWS = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // NBUF x [K image | V image]
 
     const int seq = blockIdx.z, kvh = blockIdx.y, qt = blockIdx.x;
     const int S = p.seq_len[seq];
@@ -69,31 +95,65 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
     if (qt * QROWS >= R) return;
     const int tok0 = p.seq_tok_start[seq], pos0 = p.seq_pos[seq];
     const int32_t* tbl = p.blk_table + (int64_t)seq * p.tbl_stride;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fq = lane & 15, fg = lane >> 4;
 
-    // ---- this lane's query rows (one per sub-tile) ----
-    bool row_ok[TQ];
-    int s_idx[TQ], head[TQ], limit[TQ];
+    // ---- this lane's query rows (one per sub-tile); position and head are re-derived where needed (registers) ----
     bf16x8 qf[TQ][KS];
+    auto row_of = [&](int qi, bool& ok) {
+        int row = qt * QROWS + (wave * TQ + qi) * 16 + fq;
+        ok = row < R;
+        return ok ? row : qt * QROWS;          // clamp to a valid row; result discarded
+    };
 #pragma unroll
     for (int qi = 0; qi < TQ; qi++) {
-        int row = qt * QROWS + (wave * TQ + qi) * 16 + fq;
-        row_ok[qi] = row < R;
-        if (!row_ok[qi]) row = qt * QROWS;     // clamp to a valid row; result discarded
-        s_idx[qi] = row / p.group;
-        head[qi] = kvh * p.group + (row - s_idx[qi] * p.group);
-        limit[qi] = pos0 + s_idx[qi];          // last key this row may attend to (causal)
-        const bf16_t* qp = (const bf16_t*)p.q + (int64_t)(tok0 + s_idx[qi]) * p.q_stride + head[qi] * HD;
+        bool ok;
+        const int row = row_of(qi, ok), si = row / p.group, hd_ = kvh * p.group + (row - si * p.group);
+        const bf16_t* qp = (const bf16_t*)p.q + (int64_t)(tok0 + si) * p.q_stride + hd_ * HD;
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) qf[qi][ks] = *(const bf16x8*)(qp + ks * 32 + fg * 8);
     }
-
-    // last key any row of this workgroup needs
     int last_row = qt * QROWS + QROWS - 1;
     if (last_row > R - 1) last_row = R - 1;
-    const int kmax = pos0 + last_row / p.group;
-    const int n_kt = kmax / 64 + 1;
+    const int n_kt = (pos0 + last_row / p.group) / 64 + 1;
+    // key tiles this WAVE needs: up to its last valid row's causal limit (none when the wave has no valid row)
+    const int w_row0 = qt * QROWS + wave * 32;
+    int w_last = w_row0 + 31;
+    if (w_last > R - 1) w_last = R - 1;
+    const int wave_n_kt = w_row0 < R ? (pos0 + w_last / p.group) / 64 + 1 : 0;
+    const int wave_first_limit = pos0 + w_row0 / p.group;     // tiles wholly below it need no masking
+
+    // ---- LDS-DMA: wave w moves pieces w*PW .. w*PW+PW-1 of each tile's [K pieces | V pieces] list ----
+    int src_off[PW];                 // element offset of this lane's 16 bytes inside the (K or V) tile
+#pragma unroll
+    for (int i = 0; i < PW; i++) {
+        const int jj = (wave * PW + i) % PIECES;
+        const int pos16 = jj * 64 + lane, row = pos16 / CPR, pc = pos16 % CPR;
+        const int c = (((pc >> 1) ^ kv_swz<HD>(row)) << 1) | (pc & 1);
+        src_off[i] = row * HD + c * 8;
+    }
+    auto issue = [&](int kt, int buf) {
+        const int bi = kv_block_index(p, kt * 64), krow0 = kt * 64 - bi * p.Tmax;      // (64 | Tmax: no straddling)
+        const int64_t blk_off = (int64_t)tbl[bi] * p.slot_stride + ((int64_t)kvh * p.Tmax + krow0) * HD;
+        char* dst = smem + buf * (2 * TILE_BYTES) + wave * (PW * 1024);               // (K pieces first, then V pieces)
+#pragma unroll
+        for (int i = 0; i < PW; i++) {
+            const bool is_v = (wave * PW + i) >= PIECES;
+            const bf16_t* base = (const bf16_t*)(is_v ? p.vcache : p.kcache) + blk_off;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + src_off[i]),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside a K / V image) ----
+    int k_off[KS];                    // row 16t + fq: + t * 16 rows
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) k_off[ks] = 16 * kv_img_chunk<HD>(fq, ks * 4 + fg);
+    const int q4 = fq >> 2, p4 = fq & 3;
+    int v_off[DT];                    // row 4 fg + q4 (+ 32 u, + 16): 32-byte segment d, half p4 & 1
+#pragma unroll
+    for (int d = 0; d < DT; d++) v_off[d] = 16 * kv_img_chunk<HD>(4 * fg + q4, 2 * d + (p4 >> 1)) + 8 * (p4 & 1);
 
     f32x4 o[TQ][DT];
     float m_run[TQ], l_run[TQ];
@@ -103,49 +163,27 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
 #pragma unroll
         for (int d = 0; d < DT; d++) o[qi][d] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // softmax in the exp2 domain: scores are scaled by scale * log2(e) once, so every exponential is one v_exp_f32
-    const float sl2 = p.scale * 1.4426950408889634f;
-    // first key tile that any row of this WAVE may not see completely (causal): tiles below it need no masking
-    const int wave_first_limit = pos0 + (qt * QROWS + wave * TQ * 16) / p.group;
+    const float sl2 = p.scale * 1.4426950408889634f;     // exp2 domain
 
-    // K/V tiles are fetched one tile ahead into registers (64 B per thread), so the global latency of tile kt+1 runs
-    // under the MFMAs and softmax of tile kt; the LDS image is refreshed between two barriers
-    constexpr int KCH = HD / 8;                      // 16-B chunks per K row
-    constexpr int KPT = 64 * KCH / 256, VPT = HD * 8 / 256;     // chunks per thread: K tile, V^T tile
-    bf16x8 kreg[KPT], vreg[VPT];
-    auto fetch = [&](int kt) {
-        const int bi = kv_block_index(p, kt * 64), krow0 = kt * 64 - bi * p.Tmax;      // (64 | Tmax: no straddling)
-        const int64_t blk_off = (int64_t)tbl[bi] * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
-        const bf16_t* kbase = (const bf16_t*)p.kcache + blk_off + (int64_t)krow0 * HD;     // K rows of the tile
-        const bf16_t* vbase = (const bf16_t*)p.vcache + blk_off + krow0;                    // V^T columns of the tile
-#pragma unroll
-        for (int i = 0; i < KPT; i++) {
-            const int c = tid + i * 256, r = c / KCH, cc = c % KCH;
-            kreg[i] = *(const bf16x8*)(kbase + (int64_t)r * HD + cc * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < VPT; i++) {
-            const int c = tid + i * 256, r = c >> 3, cc = c & 7;
-            vreg[i] = *(const bf16x8*)(vbase + (int64_t)r * p.Tmax + cc * 8);
-        }
-    };
-    fetch(0);
+    issue(0, 0);
+    if (n_kt > 1) issue(1, 1);
+    int buf = 0;
     for (int kt = 0; kt < n_kt; kt++) {
-        __syncthreads();                             // every wave is done reading the previous tile's LDS image
-#pragma unroll
-        for (int i = 0; i < KPT; i++) {
-            const int c = tid + i * 256, r = c / KCH, cc = c % KCH;
-            *(bf16x8*)(Ks + r * KROW + cc * 8) = kreg[i];
+        // my pieces of tile kt have landed (tile kt+1's may stay in flight)
+        if (kt + 1 < n_kt) {
+            if (PW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-#pragma unroll
-        for (int i = 0; i < VPT; i++) {
-            const int c = tid + i * 256, r = c >> 3, cc = c & 7;
-            *(bf16x8*)(Vts + r * VROW + cc * 8) = vreg[i];
-        }
-        if (kt + 1 < n_kt) fetch(kt + 1);            // in flight during this tile's compute
-        __syncthreads();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < n_kt) { int nb = buf + 2; if (nb >= NBUF) nb -= NBUF; issue(kt + 2, nb); }
+        const char* kimg = smem + buf * (2 * TILE_BYTES);
+        const char* vimg = kimg + TILE_BYTES;
+        buf = buf + 1 == NBUF ? 0 : buf + 1;
+        if (kt >= wave_n_kt) continue;                   // (wave-uniform) every row of this wave is masked out here
 
-        // ---- S^T = K · Q^T : 4 sub-tiles of 16 keys, each K fragment used for all TQ query sub-tiles ----
+        // ---- S^T = K · Q^T : 4 sub-tiles of 16 keys, each K fragment used for both query sub-tiles ----
         f32x4 s[TQ][4];
 #pragma unroll
         for (int qi = 0; qi < TQ; qi++)
@@ -155,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
         for (int t = 0; t < 4; t++)
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
-                const bf16x8 kf = *(const bf16x8*)(Ks + (t * 16 + fq) * KROW + ks * 32 + fg * 8);
+                const bf16x8 kf = *(const bf16x8*)(kimg + k_off[ks] + t * (16 * CPR * 16));
 #pragma unroll
                 for (int qi = 0; qi < TQ; qi++)
                     s[qi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], s[qi][t], 0, 0, 0);
@@ -172,22 +210,21 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
                     tmax = fmaxf(tmax, fmaxf(fmaxf(s[qi][t][0], s[qi][t][1]), fmaxf(s[qi][t][2], s[qi][t][3])));
                 }
             } else {
+                bool ok;
+                const int lim = pos0 + row_of(qi, ok) / p.group - kt * 64 - fg * 4;   // last key (tile-relative) this row may see
 #pragma unroll
                 for (int t = 0; t < 4; t++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const int key = kt * 64 + t * 16 + fg * 4 + r;
                         float v = s[qi][t][r] * sl2;
-                        v = (key <= limit[qi]) ? v : -INFINITY;      // reference: -1e10 then exp() == 0 exactly
+                        v = (t * 16 + r <= lim) ? v : -INFINITY;     // reference: -1e10 then exp() == 0 exactly
                         s[qi][t][r] = v;
                         tmax = fmaxf(tmax, v);
                     }
             }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run[qi], tmax);
-            // a sub-tile whose rows see nothing yet (its causal limit lies before this tile AND before every earlier
-            // one) cannot occur: tile 0 always holds key 0 <= limit, so m_new is finite from the first tile on
+            const float m_new = fmaxf(m_run[qi], tmax);   // finite from the first tile on: key 0 <= limit
             float psum = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; t++)
@@ -207,7 +244,8 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
             m_run[qi] = m_new;
         }
 
-        // ---- O^T += V^T · P^T : k index permuted identically on both operands; each V^T fragment used TQ times ----
+        // ---- O^T += V^T · P^T : the V^T operand comes out of the row-major V image by transposed LDS reads; the k index
+        // (keys 32u + 4fg + r, then 32u + 16 + 4fg + r) is permuted identically on both operands ----
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             bf16x8 pf[TQ];
@@ -220,9 +258,8 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
                 }
 #pragma unroll
             for (int d = 0; d < DT; d++) {
-                const bf16_t* vr = Vts + (d * 16 + fq) * VROW + u * 32 + fg * 4;
-                const bf16x4 lo = *(const bf16x4*)(vr);
-                const bf16x4 hi = *(const bf16x4*)(vr + 16);
+                const bf16x4 lo = lds_read_tr4(vimg + v_off[d] + u * (32 * CPR * 16));
+                const bf16x4 hi = lds_read_tr4(vimg + v_off[d] + u * (32 * CPR * 16) + 16 * CPR * 16);
                 bf16x8 vf;
 #pragma unroll
                 for (int r = 0; r < 4; r++) { vf[r] = lo[r]; vf[4 + r] = hi[r]; }
@@ -238,21 +275,28 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs p) {
         float l = l_run[qi];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
-        if (!row_ok[qi]) continue;
+        bool ok;
+        const int row = row_of(qi, ok), si = row / p.group, hd_ = kvh * p.group + (row - si * p.group);
+        if (!ok) continue;
         const float inv = 1.0f / l;
 #pragma unroll
         for (int d = 0; d < DT; d++)    // O[q][d = 16d + 4fg + r], written in the next GEMM's operand layout
-            act_store4<bf16_t>((bf16_t*)p.out, tok0 + s_idx[qi], head[qi] * HD + d * 16 + fg * 4, p.out_stride, o[qi][d] * inv);
+            act_store4<bf16_t>((bf16_t*)p.out, tok0 + si, hd_ * HD + d * 16 + fg * 4, p.out_stride, o[qi][d] * inv);
     }
 }
+template <int HD> constexpr int attn_prefill_lds_bytes() { return 3 * 2 * 64 * HD * 2; }
 
 // ------------------------------------------------------------------------------------------
 // bf16 decode kernel (one new token per sequence, group <= 16 query heads per kv head).
-// HBM/latency-bound KV read: one workgroup per (sequence, kv head); its NW waves take the 64-key
-// tiles round-robin (split-T inside the workgroup), each with its own online-softmax state, K and
-// V^T fragments loaded straight HBM -> VGPR (nothing is shared between waves, so no LDS staging
-// and no barrier in the loop), and the NW partial results are merged once through LDS
-// (flash-decoding combine, fixed wave order).  Same transposed MFMA dataflow as the prefill kernel.
+// HBM/latency-bound KV read: one workgroup per (sequence, kv head); its NW waves take the 64-key tiles round-robin
+// (split-T inside the workgroup), each with its own online-softmax state; nothing is shared between waves, so there
+// is no LDS staging and no barrier in the loop, and the NW partial results are merged once through LDS
+// (flash-decoding combine, fixed wave order).
+//   S^T = K · Q^T on MFMA (K fragments straight HBM -> VGPR: 16 rows x 64 B per instruction);
+//   V is read as WHOLE ROWS: lane (ksub = lane / CPR, dch = lane % CPR) loads chunk dch of key row i*KPI + ksub, so
+//   every load instruction is one contiguous KiB of the row-major V slab and the append of the new token's V is one
+//   contiguous row; the rows then pass through a wave-private LDS image (the prefill kernel's image) and come back
+//   as the V^T MFMA operand by transposed reads, so P·V is 8 MFMAs per tile with P^T straight from the accumulators.
 // ------------------------------------------------------------------------------------------
 // rotate one (lo, hi) pair of 8-wide chunks: lo = d0..d0+7 (< HD/2), hi = the same offsets + HD/2
 __device__ __forceinline__ void rope_pair8(const float* row, const float* cs, const float* sn, int d0, int half,
@@ -275,22 +319,27 @@ __device__ __forceinline__ void rope_pair8(const float* row, const float* cs, co
 
 template <int HD, int NW, bool FUSED>
 __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
-    constexpr int KS = HD / 32, DT = HD / 16, HALF = HD / 2;
+    constexpr int KS = HD / 32, DT = HD / 16, HALF = HD / 2, CPR = HD / 8, KPI = 64 / CPR, NVL = 64 / KPI;
+    constexpr int NT2 = HD <= 64 ? 2 : 1;                    // key tiles whose loads are in flight together, per wave
+    constexpr int TILE_BYTES = 64 * HD * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [NW] wave-private V images (later: the partial O^T)
     __shared__ float red_m[NW][16];
     __shared__ float red_l[NW][16];
-    __shared__ f32x4 red_o[NW][DT][64];
     const int seq = blockIdx.y, kvh = blockIdx.x;
     const int32_t* tbl = p.blk_table + (int64_t)seq * p.tbl_stride;
     const int tok = p.seq_tok_start[seq], pos0 = p.seq_pos[seq];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fq = lane & 15, fg = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fq = lane & 15, fg = lane >> 4;                // MFMA role: query head fq, k group fg
+    const int dch = lane % CPR, ksub = lane / CPR;           // row role: 16-byte chunk dch of key row ksub (+ i*KPI)
     const bool row_ok = fq < p.group;
     const int head = kvh * p.group + (row_ok ? fq : 0);
+    char* vimg = smem + wave * TILE_BYTES;
     bf16x8 qf[KS];
     const int n_kt = pos0 / 64 + 1;
-    // FUSED: the new token's K row (RoPE applied) as this lane's operand chunks, and its V values for this lane's d
+    // FUSED: the new token's K row (RoPE applied) as this lane's MFMA operand chunks, and chunk dch of its V row
     bf16x8 knew[KS];
-    bf16_t vnew[DT];
+    bf16x8 vnew8;
     if (FUSED) {
         const float* row = p.qkv + (int64_t)tok * p.qkv_stride;
         const float* cs = p.cos_t ? p.cos_t + (int64_t)pos0 * HD : nullptr;
@@ -300,9 +349,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
             rope_pair8(row + head * HD, cs, sn, ks * 32 + fg * 8, HALF, qf[ks], qf[ks + KS / 2]);
             rope_pair8(row + (p.nH + kvh) * HD, cs, sn, ks * 32 + fg * 8, HALF, knew[ks], knew[ks + KS / 2]);
         }
-        const float* vrow = row + (p.nH + p.nKV + kvh) * HD;
+        const float* vrow = row + (p.nH + p.nKV + kvh) * HD + dch * 8;
+        const f32x4 v0 = *(const f32x4*)vrow, v1 = *(const f32x4*)(vrow + 4);
 #pragma unroll
-        for (int d = 0; d < DT; d++) vnew[d] = (bf16_t)vrow[d * 16 + fq];
+        for (int e = 0; e < 4; e++) { vnew8[e] = (bf16_t)v0[e]; vnew8[4 + e] = (bf16_t)v1[e]; }
     } else {
         const bf16_t* qp = (const bf16_t*)p.q + (int64_t)tok * p.q_stride + head * HD;
 #pragma unroll
@@ -312,17 +362,22 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
     f32x4 o[DT];
 #pragma unroll
     for (int d = 0; d < DT; d++) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;     // exp2 domain
+    const float sl2 = p.scale * 1.4426950408889634f;
+    // LDS offsets: where this lane's V chunks go (row i*KPI + ksub, chunk dch) and where its transposed reads come from
+    // (row i*KPI + ksub: the swizzle pattern only depends on i & 1, so two bases + compile-time row offsets)
+    const int w_base[2] = {16 * kv_img_chunk<HD>(ksub, dch), 16 * kv_img_chunk<HD>(KPI + ksub, dch) - 16 * KPI * CPR};
+    const int q4 = fq >> 2, p4 = fq & 3;
+    int v_off[DT];
+#pragma unroll
+    for (int d = 0; d < DT; d++) v_off[d] = 16 * kv_img_chunk<HD>(4 * fg + q4, 2 * d + (p4 >> 1)) + 8 * (p4 & 1);
 
-    // Each wave owns key tiles wave, wave+NW, ...; the loads of TWO of its tiles are issued before either is used
-    // (a decode step is latency-bound: ~150 KB per workgroup), so sequences up to 2*NW*64 keys take one round trip.
-    constexpr int NT2 = HD <= 64 ? 2 : 1;      // hd 128: one tile's operands already fill the register budget
     // the block ids of this wave's first tiles do not depend on the sequence length: fetch them beside it, not after it
     int first_blk[NT2];
 #pragma unroll
     for (int h = 0; h < NT2; h++) first_blk[h] = tbl[min(kv_block_index(p, (wave + h * NW) * 64), p.tbl_stride - 1)];
     bf16x8 kf[NT2][4][KS];
-    bf16x4 vlo[NT2][2][DT], vhi[NT2][2][DT];
+    bf16x8 vch[NT2][NVL];
     for (int kt0 = wave; kt0 < n_kt; kt0 += NT2 * NW) {
 #pragma unroll
         for (int h = 0; h < NT2; h++) {
@@ -330,27 +385,28 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
             if (kt >= n_kt) continue;
             const int bi = kv_block_index(p, kt * 64), krow0 = kt * 64 - bi * p.Tmax;     // the KV block holding this tile
             const int blk = kt0 == wave ? first_blk[h] : tbl[bi];
-            const int64_t blk_off = (int64_t)blk * p.slot_stride + (int64_t)kvh * p.Tmax * HD;
-            const bf16_t* kbase = (const bf16_t*)p.kcache + blk_off + (int64_t)krow0 * HD;
-            const bf16_t* vbase = (const bf16_t*)p.vcache + blk_off + krow0;
+            const int64_t blk_off = (int64_t)blk * p.slot_stride + ((int64_t)kvh * p.Tmax + krow0) * HD;
+            const bf16_t* kbase = (const bf16_t*)p.kcache + blk_off;
+            const bf16_t* vbase = (const bf16_t*)p.vcache + blk_off;
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++)
                     kf[h][t][ks] = *(const bf16x8*)(kbase + (int64_t)(t * 16 + fq) * HD + ks * 32 + fg * 8);
 #pragma unroll
-            for (int u = 0; u < 2; u++)
-#pragma unroll
-                for (int d = 0; d < DT; d++) {
-                    const bf16_t* vr = vbase + (int64_t)(d * 16 + fq) * p.Tmax + u * 32 + fg * 4;
-                    vlo[h][u][d] = *(const bf16x4*)(vr);
-                    vhi[h][u][d] = *(const bf16x4*)(vr + 16);
-                }
+            for (int i = 0; i < NVL; i++) vch[h][i] = *(const bf16x8*)(vbase + (int64_t)lane * 8 + i * 512);   // 1 KiB, contiguous
         }
+        // ---- scores of the round's tiles ----
+        f32x4 s[NT2][4];
+        float tmax = -INFINITY;
 #pragma unroll
         for (int h = 0; h < NT2; h++) {
             const int kt = kt0 + h * NW;
-            if (kt >= n_kt) continue;
+            if (kt >= n_kt) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) s[h][t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                continue;
+            }
             if (FUSED && kt == n_kt - 1) {
                 // the tile that holds key pos0: its slab row is not written yet (or not visible): patch the operands
                 const int kl = pos0 & 63;
@@ -360,62 +416,64 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
 #pragma unroll
                         for (int ks = 0; ks < KS; ks++) kf[h][t][ks] = knew[ks];
                     }
-                const int r32 = kl & 31, hi_half = r32 >> 4, fg0 = (r32 & 15) >> 2, j0 = r32 & 3;
 #pragma unroll
-                for (int u = 0; u < 2; u++)
-#pragma unroll
-                    for (int d = 0; d < DT; d++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            if (u == (kl >> 5) && fg == fg0 && j == j0) {
-                                if (hi_half) vhi[h][u][d][j] = vnew[d]; else vlo[h][u][d][j] = vnew[d];
-                            }
+                for (int i = 0; i < NVL; i++)
+                    if (i == kl / KPI && ksub == kl % KPI) vch[h][i] = vnew8;
             }
-            f32x4 s[4];
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < KS; ks++) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[h][t][ks], qf[ks], s[t], 0, 0, 0);
-            }
-            float tmax = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < 4; t++)
+                for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[h][t][ks], qf[ks], acc, 0, 0, 0);
+                const int lim = pos0 - kt * 64 - fg * 4;      // last visible key, relative to this lane's first
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int key = kt * 64 + t * 16 + fg * 4 + r;
-                    float v = s[t][r] * p.scale;
-                    v = (key <= pos0) ? v : -INFINITY;
-                    s[t][r] = v;
+                    float v = acc[r] * sl2;
+                    v = (t * 16 + r <= lim) ? v : -INFINITY;
+                    acc[r] = v;
                     tmax = fmaxf(tmax, v);
                 }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run, tmax);     // finite: every tile kt < n_kt holds key kt*64 <= pos0
-            const float alpha = __expf(m_run - m_new);
-            float psum = 0.f;
+                s[h][t] = acc;
+            }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);     // finite: the round's first tile kt0 < n_kt holds key kt0*64 <= pos0
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int h = 0; h < NT2; h++)
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float pv = __expf(s[t][r] - m_new);
-                    s[t][r] = pv;
+                    const float pv = __builtin_amdgcn_exp2f(s[h][t][r] - m_new);
+                    s[h][t][r] = pv;
                     psum += pv;
                 }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
 #pragma unroll
-            for (int d = 0; d < DT; d++) o[d] *= alpha;
+        for (int d = 0; d < DT; d++) o[d] *= alpha;
+        // ---- O^T += V^T · P^T: the tile's V rows go through this wave's LDS image and come back as the transposed
+        // MFMA operand (ds_read_b64_tr_b16); a wave's LDS accesses execute in order, so no barrier ----
+#pragma unroll
+        for (int h = 0; h < NT2; h++) {
+            if (kt0 + h * NW >= n_kt) continue;
+#pragma unroll
+            for (int i = 0; i < NVL; i++) *(bf16x8*)(vimg + w_base[i & 1] + i * (16 * KPI * CPR)) = vch[h][i];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 bf16x8 pf;
 #pragma unroll
-                for (int r = 0; r < 4; r++) { pf[r] = (bf16_t)s[2 * u][r]; pf[4 + r] = (bf16_t)s[2 * u + 1][r]; }
+                for (int r = 0; r < 4; r++) { pf[r] = (bf16_t)s[h][2 * u][r]; pf[4 + r] = (bf16_t)s[h][2 * u + 1][r]; }
 #pragma unroll
                 for (int d = 0; d < DT; d++) {
+                    const bf16x4 lo = lds_read_tr4(vimg + v_off[d] + u * (32 * CPR * 16));
+                    const bf16x4 hi = lds_read_tr4(vimg + v_off[d] + u * (32 * CPR * 16) + 16 * CPR * 16);
                     bf16x8 vf;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { vf[r] = vlo[h][u][d][r]; vf[4 + r] = vhi[h][u][d][r]; }
+                    for (int r = 0; r < 4; r++) { vf[r] = lo[r]; vf[4 + r] = hi[r]; }
                     o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[d], 0, 0, 0);
                 }
             }
@@ -426,22 +484,21 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
         // the register copies), so the loads above are not ordered behind these stores
         int nblk, nrow;
         kv_locate(tbl, 0, pos0, p.Tmax, nblk, nrow);
+        const int64_t noff = (int64_t)nblk * p.slot_stride + ((int64_t)kvh * p.Tmax + nrow) * HD;
         if (wave == 0 && fq == 0) {      // lanes fg = 0..3 of column 0 hold all of K_new between them
-            bf16_t* kd = (bf16_t*)p.kcache + (int64_t)nblk * p.slot_stride + ((int64_t)kvh * p.Tmax + nrow) * HD;
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) *(bf16x8*)(kd + ks * 32 + fg * 8) = knew[ks];
+            for (int ks = 0; ks < KS; ks++) *(bf16x8*)((bf16_t*)p.kcache + noff + ks * 32 + fg * 8) = knew[ks];
         }
-        if (wave == 1 % NW && fg == 0) {  // lanes fq = 0..15 hold V_new[16d + fq]
-            bf16_t* vd = (bf16_t*)p.vcache + (int64_t)nblk * p.slot_stride + (int64_t)kvh * p.Tmax * HD + nrow;
-#pragma unroll
-            for (int d = 0; d < DT; d++) vd[(int64_t)(d * 16 + fq) * p.Tmax] = vnew[d];
-        }
+        if (wave == 1 % NW && ksub == 0)  // lanes dch = 0..CPR-1 hold the V row: one contiguous row
+            *(bf16x8*)((bf16_t*)p.vcache + noff + dch * 8) = vnew8;
     }
+    // ---- flash-decoding combine through LDS (the partial O^T overwrites this wave's own V image), fixed wave order ----
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     if (fg == 0) { red_m[wave][fq] = m_run; red_l[wave][fq] = l_run; }
+    f32x4* my_o = (f32x4*)vimg;                              // [DT][64 lanes]
 #pragma unroll
-    for (int d = 0; d < DT; d++) red_o[wave][d][lane] = o[d];
+    for (int d = 0; d < DT; d++) my_o[d * 64 + lane] = o[d];
     __syncthreads();
     if (wave != 0 || !row_ok) return;
     float mstar = red_m[0][fq];
@@ -453,10 +510,11 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
     for (int d = 0; d < DT; d++) O[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < NW; w++) {
-        const float sc = __expf(red_m[w][fq] - mstar);   // idle waves: exp(-inf) = 0
+        const float sc = __builtin_amdgcn_exp2f(red_m[w][fq] - mstar);   // idle waves: exp2(-inf) = 0
         L += red_l[w][fq] * sc;
+        const f32x4* wo = (const f32x4*)(smem + w * TILE_BYTES);
 #pragma unroll
-        for (int d = 0; d < DT; d++) O[d] += red_o[w][d][lane] * sc;
+        for (int d = 0; d < DT; d++) O[d] += wo[d * 64 + lane] * sc;
     }
     const float inv = 1.0f / L;
 #pragma unroll

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void norm_row_kernel(float* __restrict__ x,
 
 // ---------------------------------------------------------------------------------------
 // RoPE (rope.go:153-205) on Q and K as they leave the fused QKV GEMM, plus the KV append that
-// replaces Concatenate (tensor.go:283-321): K -> slab[pos][hd], V -> slab (bf16: V^T [hd][pos]).
+// replaces Concatenate (tensor.go:283-321): K -> slab[pos][hd], V -> slab[pos][hd] (VT = true would write V^T: unused).
 // qkv is fp32 [tokens][(nH+2nKV)*HD] = [Q heads | K heads | V heads].
 // grid = (tokens, nH + 2*nKV), block = HD/2 threads... one thread per rotation pair.
 // ---------------------------------------------------------------------------------------

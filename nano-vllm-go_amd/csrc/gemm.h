@@ -35,7 +35,7 @@ enum GemmEpi {
     EPI_SWIGLU = 2,  // C[m, f] = silu(gate) * up        W rows interleaved (transformer.go:50-66)
     EPI_GELU = 3,    // C = gelu_tanh(acc + bias)                           (transformer.go:67-78)
     EPI_QKV = 4,     // fused QKV projection epilogue (head_dim 64): bias, RoPE on Q and K (rope.go:153-205),
-                     // Q -> q buffer, K -> KV slab [pos][hd], V -> slab V^T [hd][pos]  (replaces the fp32 qkv
+                     // Q -> q buffer, K and V -> their KV slabs [pos][hd]  (replaces the fp32 qkv
                      // round trip + rope_kv_kernel in prefill; Concatenate tensor.go:283-321)
 };
 
@@ -201,24 +201,17 @@ __device__ __forceinline__ void epilogue_qkv_head(const GemmArgs& p, int m, int 
     }
     int blk = 0, row = 0;
     if (head >= q.nH) kv_locate(q.blk_table, q.tok_tbl[m], pos, q.Tmax, blk, row);
-    if (head < q.nH + q.nKV) {
-        bf16_t* dst = head < q.nH
-            ? q.q_out + (int64_t)m * (q.nH * HD) + head * HD + 4 * fg
-            : q.kcache + (int64_t)blk * q.slot_stride + ((int64_t)(head - q.nH) * q.Tmax + row) * HD + 4 * fg;
+    // Q -> q buffer; K and V -> their slabs, both row-major [pos][hd] (kv_cache.go:5-6)
+    bf16_t* dst;
+    if (head < q.nH) dst = q.q_out + (int64_t)m * (q.nH * HD) + head * HD + 4 * fg;
+    else if (head < q.nH + q.nKV) dst = q.kcache + (int64_t)blk * q.slot_stride + ((int64_t)(head - q.nH) * q.Tmax + row) * HD + 4 * fg;
+    else dst = q.vcache + (int64_t)blk * q.slot_stride + ((int64_t)(head - q.nH - q.nKV) * q.Tmax + row) * HD + 4 * fg;
 #pragma unroll
-        for (int j = 0; j < TH; j++) {
-            bf16x4 o;
+    for (int j = 0; j < TH; j++) {
+        bf16x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; r++) o[r] = (bf16_t)t[j][r];
-            *(bf16x4*)(dst + 16 * j) = o;
-        }
-    } else {
-        const int kvh = head - q.nH - q.nKV;
-        bf16_t* dst = q.vcache + (int64_t)blk * q.slot_stride + (int64_t)kvh * q.Tmax * HD + row;
-#pragma unroll
-        for (int j = 0; j < TH; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) dst[(int64_t)(16 * j + 4 * fg + r) * q.Tmax] = (bf16_t)t[j][r];
+        for (int r = 0; r < 4; r++) o[r] = (bf16_t)t[j][r];
+        *(bf16x4*)(dst + 16 * j) = o;
     }
 }
 

@@ -867,8 +867,7 @@ void norm(nvl_model* m, float* x, const int32_t* rows_idx, const DevTensor& w, c
 }
 
 static int g_attn_nw = 0;      // nvl_set_tuning key 15: waves per decode-attention workgroup (0 = from the context length, 2, 4, 8)
-static int g_attn_tq2 = 1;     // nvl_set_tuning key 10: two query sub-tiles per wave in the prefill attention kernel
-                               // (0 = never, 1 = when the grid still fills the chip, 2 = always)
+static int g_attn_tq2 = 1;     // nvl_set_tuning key 10: unused since round 2 (the prefill kernel always keeps two sub-tiles per wave)
 void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, double flops, bool fused_qkv = false) {
     AttnArgs a{};
     a.q = m->q; a.q_stride = m->nH * m->hd;
@@ -900,22 +899,27 @@ void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, do
         }
 #define NVL_DEC(HDv, FUSEDv)                                                                                           \
         do {                                                                                                           \
-            if (nw == 2) hipLaunchKernelGGL((attn_decode_bf16_kernel<HDv, 2, FUSEDv>), grid, dim3(128), 0, m->stream, a);      \
-            else if (nw == 4) hipLaunchKernelGGL((attn_decode_bf16_kernel<HDv, 4, FUSEDv>), grid, dim3(256), 0, m->stream, a); \
-            else hipLaunchKernelGGL((attn_decode_bf16_kernel<HDv, 8, FUSEDv>), grid, dim3(512), 0, m->stream, a);              \
+            constexpr int tile_bytes = 64 * HDv * 2;                                                                   \
+            if (nw == 2) hipLaunchKernelGGL((attn_decode_bf16_kernel<HDv, 2, FUSEDv>), grid, dim3(128), 2 * tile_bytes, m->stream, a);      \
+            else if (nw == 4) hipLaunchKernelGGL((attn_decode_bf16_kernel<HDv, 4, FUSEDv>), grid, dim3(256), 4 * tile_bytes, m->stream, a); \
+            else {                                                                                                     \
+                NVL_LDS_ATTR((attn_decode_bf16_kernel<HDv, 8, FUSEDv>), 8 * tile_bytes);                               \
+                hipLaunchKernelGGL((attn_decode_bf16_kernel<HDv, 8, FUSEDv>), grid, dim3(512), 8 * tile_bytes, m->stream, a);               \
+            }                                                                                                          \
         } while (0)
         if (fused_qkv) { if (m->hd == 64) NVL_DEC(64, true); else NVL_DEC(128, true); }
         else { if (m->hd == 64) NVL_DEC(64, false); else NVL_DEC(128, false); }
 #undef NVL_DEC
     } else {
-        // hd 64: two 16-row query sub-tiles per wave (128 rows per workgroup) once there are enough rows to fill the chip;
-        // short prompts and hd 128 (register budget) keep one
+        // 256 query rows (position x head-in-group, position-major) per workgroup of 8 waves; K/V tiles by LDS-DMA
         const int64_t qrows = (int64_t)max_len * m->group;
-        const bool tq2 = m->hd == 64 && (g_attn_tq2 == 2 || (g_attn_tq2 == 1 && cdiv(qrows, 128) * m->nKV * n_seqs >= 512));
-        dim3 grid(cdiv(qrows, tq2 ? 128 : 64), m->nKV, n_seqs);
-        if (tq2) hipLaunchKernelGGL((attn_bf16_kernel<64, 2>), grid, dim3(256), 0, m->stream, a);
-        else if (m->hd == 64) hipLaunchKernelGGL((attn_bf16_kernel<64, 1>), grid, dim3(256), 0, m->stream, a);
-        else hipLaunchKernelGGL((attn_bf16_kernel<128, 1>), grid, dim3(256), 0, m->stream, a);
+        dim3 grid(cdiv(qrows, 256), m->nKV, n_seqs);
+        if (m->hd == 64) {
+            hipLaunchKernelGGL((attn_prefill_bf16_kernel<64>), grid, dim3(512), attn_prefill_lds_bytes<64>(), m->stream, a);
+        } else {
+            NVL_LDS_ATTR(attn_prefill_bf16_kernel<128>, attn_prefill_lds_bytes<128>());
+            hipLaunchKernelGGL((attn_prefill_bf16_kernel<128>), grid, dim3(512), attn_prefill_lds_bytes<128>(), m->stream, a);
+        }
     }
     NVL_HIP(hipGetLastError());
 }
@@ -931,7 +935,7 @@ void rope_kv(nvl_model* m, int li, const Meta& md, int M) {
                            md.tok_pos, md.tok_tbl, md.blk_table, m->rope_cos, m->rope_sin, (float*)m->q, m->nH * m->hd,
                            (float*)kc, (float*)vc, m->slot_stride, m->Tmax, m->nH, m->nKV, m->hd);
     else
-        hipLaunchKernelGGL((rope_kv_kernel<bf16_t, true>), grid, dim3(thr), 0, m->stream, m->qkv, m->n_qkv,
+        hipLaunchKernelGGL((rope_kv_kernel<bf16_t, false>), grid, dim3(thr), 0, m->stream, m->qkv, m->n_qkv,
                            md.tok_pos, md.tok_tbl, md.blk_table, m->rope_cos, m->rope_sin, (bf16_t*)m->q, m->nH * m->hd,
                            (bf16_t*)kc, (bf16_t*)vc, m->slot_stride, m->Tmax, m->nH, m->nKV, m->hd);
     NVL_HIP(hipGetLastError());
@@ -1793,8 +1797,7 @@ void read_kv(nvl_model* m, const int32_t* blocks, int n_blocks, int T, int layer
                     const int r = t - bi * BS;
                     const int64_t o = ((int64_t)h * T + t) * hd + d;
                     if (k_out) k_out[o] = rd(kb, ((int64_t)h * BS + r) * hd + d);
-                    if (v_out) v_out[o] = m->f32 ? rd(vb, ((int64_t)h * BS + r) * hd + d)
-                                                 : rd(vb, ((int64_t)h * hd + d) * BS + r);   // bf16 path keeps V^T
+                    if (v_out) v_out[o] = rd(vb, ((int64_t)h * BS + r) * hd + d);
                 }
     }
 }

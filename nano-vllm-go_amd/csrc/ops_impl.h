@@ -176,7 +176,7 @@ extern "C" int nvl_op_attention(int device, int precision, const float* q, const
     nvl_model& m = cx.m;
     const int Tmax = (int)round_up(T, 64);
     if (m.f32 && Tmax > 12000) return op_fail("nvl_op_attention: T too long for the f32 kernel");
-    // token-major Q, slab-layout K, and V (bf16 path: V^T)
+    // token-major Q, slab-layout K and V
     std::vector<float> qt((size_t)S * nH * hd), kc((size_t)nKV * Tmax * hd, 0.f), vc((size_t)nKV * Tmax * hd, 0.f);
     for (int h = 0; h < nH; h++)
         for (int s = 0; s < S; s++)
@@ -185,8 +185,7 @@ extern "C" int nvl_op_attention(int device, int precision, const float* q, const
         for (int t = 0; t < T; t++)
             for (int d = 0; d < hd; d++) {
                 kc[((size_t)h * Tmax + t) * hd + d] = k[((size_t)h * T + t) * hd + d];
-                if (m.f32) vc[((size_t)h * Tmax + t) * hd + d] = v[((size_t)h * T + t) * hd + d];
-                else vc[((size_t)h * hd + d) * Tmax + t] = v[((size_t)h * T + t) * hd + d];
+                vc[((size_t)h * Tmax + t) * hd + d] = v[((size_t)h * T + t) * hd + d];
             }
     m.q = cx.up_mat(qt.data(), S, (int64_t)nH * hd, false, 1, true);
     m.kcache = cx.up_mat(kc.data(), 1, (int64_t)kc.size(), false, 1, true);

@@ -1,7 +1,7 @@
 """Aggregate a rocprofv3 kernel trace of bench.py by kernel and by PHASE.
 
 The trace is cut into forward passes at every argmax launch (the last kernels of a pass); a pass that contains the
-prefill attention kernel (attn_bf16_kernel) is a prefill pass, every other pass is a decode step.  (Round 1 printed
+prefill attention kernel (attn_prefill_bf16_kernel) is a prefill pass, every other pass is a decode step.  (Round 1 printed
 "everything between the first and the last prefill attention" as prefill, which swallowed earlier steps' decode
 kernels.)  usage: prof_decode.py <rocprofv3 output dir> [skip_passes]"""
 import collections, csv, glob, sys
@@ -29,7 +29,7 @@ if cur:
 passes = [p for p in passes if any("gemm" in r["Kernel_Name"] for r in p)][skip:]
 phases = {"prefill": [], "decode": []}
 for p in passes:
-    phases["prefill" if any("attn_bf16_kernel" in r["Kernel_Name"] for r in p) else "decode"].append(p)
+    phases["prefill" if any("attn_prefill_bf16_kernel" in r["Kernel_Name"] for r in p) else "decode"].append(p)
 for name, ps in phases.items():
     if not ps:
         continue

@@ -146,8 +146,9 @@ def test_attention(gpu, oracle, nH, nKV, S, T, precision):
 @pytest.mark.parametrize("nH,nKV,S,T", [(4, 2, 5, 5), (2, 2, 33, 100), (3, 1, 7, 64), (71, 1, 2, 130), (8, 2, 130, 130),
                                         (4, 2, 300, 1400), (8, 2, 257, 257)])
 def test_attention_two_query_subtiles_per_wave(gpu, oracle, nH, nKV, S, T):
-    """attn_bf16_kernel<64, 2> (128 query rows per workgroup: the form large prefill batches take), forced on small
-    shapes: ragged row counts, rows past the end of a sub-tile, diagonal and fully visible key tiles."""
+    """attn_prefill_bf16_kernel (256 query rows per workgroup, two 16-row sub-tiles per wave) on small shapes: ragged row
+    counts, rows past the end of a sub-tile, waves without a valid row, diagonal and fully visible key tiles, more key
+    tiles than the 3-slot LDS ring."""
     r = rng(nH * 10 + T)
     q = r.standard_normal((nH, S, 64), dtype=np.float32)
     k = r.standard_normal((nKV, T, 64), dtype=np.float32)
@@ -162,7 +163,9 @@ def test_attention_two_query_subtiles_per_wave(gpu, oracle, nH, nKV, S, T):
 
 @pytest.mark.parametrize("nH,nKV,S,T,hd", [(8, 2, 1, 2100, 64),      # decode: > 1024 keys -> the split-T loop runs twice per wave
                                             (4, 4, 1, 1100, 64), (4, 1, 1, 1500, 128),
-                                            (4, 2, 300, 1400, 64)])  # chunked prefill against a long cache
+                                            (8, 1, 1, 300, 64), (12, 2, 1, 1300, 64), (16, 1, 1, 200, 128),   # 5..16 query heads per kv head
+                                            (4, 2, 300, 1400, 64),   # chunked prefill against a long cache
+                                            (4, 2, 200, 900, 128), (2, 2, 520, 520, 128)])   # hd 128 through the LDS ring
 def test_attention_long_context(gpu, oracle, nH, nKV, S, T, hd):
     r = rng(T)
     q = r.standard_normal((nH, S, hd), dtype=np.float32)
