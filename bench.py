@@ -210,7 +210,7 @@ def main():
     seqs_per_call = max(1, max_batch_tokens // S)
     sample_u = rng.random((G, B)).astype(np.float32)
 
-    def one_step(profile_prefill: bool):
+    def one_step(profile_prefill: bool, profile_decode: bool = False):
         """prefill all B prompts, then G decode steps; returns (prefill_s, decode_s)."""
         for sid in seq_ids:
             model.seq_reset(sid)
@@ -222,7 +222,7 @@ def main():
             ids = seq_ids[b0:b0 + seqs_per_call]
             _, am = model.forward_batch(ids, [prompts[i] for i in ids], [0] * len(ids), want_logits=False)
             nxt[b0:b0 + len(ids)] = am
-        model.set_profile(False)
+        model.set_profile(profile_decode)
         t_b = time.perf_counter()
         if args.decode == "fused":
             model.decode_greedy(seq_ids, nxt, G)
@@ -234,6 +234,7 @@ def main():
                 _, am = model.forward_batch(seq_ids, [[int(t)] for t in nxt], [S + g] * B, want_logits=False)
                 nxt = am
         t_c = time.perf_counter()
+        model.set_profile(False)
         return t_b - t_a, t_c - t_b
 
     for _ in range(args.warmup):
@@ -258,6 +259,29 @@ def main():
     elapsed, pre_s, dec_s = pkg.dist.max_over_ranks([elapsed, pre_s, dec_s],
                                                     device="cpu" if args.rehearse_on_one_gpu else device)
     st = model.stats()
+    # Per-kernel view: ONE more step of the same workload AFTER the timed region with HIP events around every launch of
+    # both phases (events in the decode loop would cost the timed value a few percent).  nvl_get_kernel_stats: per
+    # launch site, launches, device time and algorithmic work.
+    kernels = []
+    if rank == 0:
+        model.reset_stats()
+        one_step(True, True)
+        ks = model.kernel_stats()
+        tot_ms = sum(k["ms"] for k in ks) or 1.0
+        for k in sorted(ks, key=lambda k: -k["ms"]):
+            if k["ms"] / tot_ms < 0.004:
+                continue
+            us = 1e3 * k["ms"] / k["launches"]
+            tf = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+            gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+            mfma_bound = k["phase"] == "prefill" and k["site"] in ("qkv_proj", "o_proj", "ffn_up", "ffn_down", "attention",
+                                                                   "moe_up", "moe_down", "lm_head") and tf / MFMA_BF16_PEAK_TFLOPS > gbs / HBM_PEAK_GBS
+            e = {"site": k["site"], "phase": k["phase"], "launches": k["launches"], "avg_launch_us": round(us, 2),
+                 "share_of_step": round(k["ms"] / tot_ms, 4), "bound": "mfma" if mfma_bound else "hbm",
+                 "flops_per_launch": round(k["flops"] / k["launches"]), "bytes_per_launch": round(k["bytes"] / k["launches"]),
+                 "achieved_tflops": round(tf, 1), "achieved_gbs": round(gbs, 1)}
+            e["frac"] = round(tf / MFMA_BF16_PEAK_TFLOPS if mfma_bound else gbs / HBM_PEAK_GBS, 4)
+            kernels.append(e)
 
     tokens_per_step = B * S + B * G
     nrep = 1 if tp else world          # tensor parallel: ONE batch for the whole group
@@ -274,13 +298,32 @@ def main():
     # HBM-side traffic of the dominant kernel class comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on
     # gfx950 + WRITE_SIZE; scripts/pmc_traffic.py), committed under profiles/ — it cannot be sampled from inside
     # this process.  null when the profile is absent or was taken on another workload.
-    traffic = None
+    # The file is used only if it was taken on THIS kernel source (hash of csrc/*.h, *.hip recorded by
+    # scripts/pmc_traffic_r02.py) and on this workload; otherwise traffic is null.
+    traffic, traffic_note, site_traffic = None, "no PMC profile for this kernel source / workload", {}
     try:
-        if args.model == "llama-3.2-1b" and (B, S) == (32, 512) and args.precision == "bf16":
-            traffic = round(json.load(open(ROOT / "profiles" / "r01e_pmc_traffic.json"))
-                            ["prefill_gemm_class_avg_bytes_per_launch"])
-    except Exception:
-        traffic = None
+        import hashlib
+        h = hashlib.sha256()
+        cdir = ROOT / "nano-vllm-go_amd" / "csrc"
+        for fn in sorted(os.listdir(cdir)):
+            if fn.endswith((".h", ".hip")):
+                h.update(fn.encode()); h.update((cdir / fn).read_bytes())
+        pmc = json.load(open(ROOT / "profiles" / "r02_pmc_traffic.json"))
+        if pmc.get("kernel_src_sha16") != h.hexdigest()[:16]:
+            traffic_note = "profiles/r02_pmc_traffic.json was taken on a different kernel source: refused"
+        elif not (args.model == "llama-3.2-1b" and (B, S) == (32, 512) and args.precision == "bf16" and not tp):
+            traffic_note = "profiles/r02_pmc_traffic.json is for llama-3.2-1b 32 x 512 bf16: refused for this workload"
+        else:
+            site_traffic = {k: round(v["hbm_bytes_per_launch"]) for k, v in pmc["sites"].items()}
+            gs = [v for k, v in pmc["sites"].items() if k in ("prefill/qkv_proj", "prefill/o_proj", "prefill/ffn_up", "prefill/ffn_down")]
+            traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in gs) / max(1, sum(v["launches"] for v in gs)))
+            traffic_note = ("bytes/launch past L2 (Infinity-Cache hits included), prefill projection class, "
+                            "profiles/r02_pmc_traffic.json (same kernel source hash)")
+    except Exception as e:      # noqa: BLE001
+        traffic, site_traffic = None, {}
+        traffic_note = f"no usable PMC profile ({type(e).__name__})"
+    for e in kernels:
+        e["traffic"] = site_traffic.get(f"{e['phase']}/{e['site']}")
 
     out = {
         "metric": "prefill + decode tokens/sec, Llama-3.2-1B bf16, 1/2/4/8 MI355X",
@@ -295,12 +338,19 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel (prefill QKV/O/FFN projections; gemm_bf16_kernel for the small LM-head GEMM)",
                      "achieved": round(gemm_tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(gemm_tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-                     "traffic_note": "bytes/launch past L2 (incl. Infinity-Cache hits), profiles/r01e_pmc_traffic.json",
+                     "traffic_note": traffic_note,
                      "launches": int(st["gemm_launches"]),
                      "avg_launch_us": round(1e3 * st["gemm_ms"] / max(1, st["gemm_launches"]), 2)},
         "decode_roofline": {"bound": "hbm", "achieved": round(dec_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
                             "note": "algorithmic weight+KV bytes per decode step / wall time per step"},
+        "kernels": kernels,
+        "kernels_note": "per launch site, from ONE extra profiled step after the timed region (HIP events around every launch on the "
+                        "library's stream; avg_launch_us is the event INTERVAL, which includes the bracket itself — about 2-3 us on this box, "
+                        "so the entries of 5-20 us decode kernels understate their rates; rocprofv3's per-kernel durations of the same "
+                        "command are in profiles/r02_bench_kernel_stats.csv / r02_phase_breakdown_b32.txt); work = algorithmic flops / bytes (weights once + operands + results; attention: every cached "
+                        "K/V once); frac vs 2.5 PFLOP/s (mfma) or 8 TB/s (hbm)",
+        "dominant_by_time": (max(kernels, key=lambda e: e["share_of_step"]) if kernels else None),
         "load_s": round(t_load, 1),
     }
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NVL_ABI_VERSION 1
+#define NVL_ABI_VERSION 2      /* 2: Mamba2 / hybrid layers (config fields, tensor kinds), nvl_stats.evictions, kernel stats */
 
 typedef enum nvl_status {
     NVL_OK = 0,
@@ -57,6 +57,11 @@ typedef struct nvl_model_config {
     int32_t tied_embedding;
     int32_t use_moe, num_experts, num_experts_per_tok;
     float   embedding_multiplier, attention_multiplier, residual_multiplier, logits_scaling;
+    /* Mamba2 / hybrid layers (config.go:100-115; Granite-4: attention + Mamba2 blocks): layer li is a Mamba2 block when
+     * bit li of mamba_layer_mask is set (HybridLayers[li] == "mamba" / "mamba2", generic_model.go:50-53, 74-76).
+     * mamba_head_dim 0 = expand * hidden / mamba_num_heads (mamba2.go:58-61).  All zero: no Mamba2 layers. */
+    int32_t  mamba_expand, mamba_state_size, mamba_num_heads, mamba_head_dim, mamba_n_groups, mamba_conv_kernel;
+    uint64_t mamba_layer_mask[2];
 } nvl_model_config;
 
 /* Arithmetic the device path computes in. */
@@ -113,6 +118,15 @@ typedef enum nvl_tensor_kind {
     NVL_T_ROUTER,          /* IN_OUT: [H, E]                               moe.go:12                */
     NVL_T_MOE_IN,          /* [E, 2I, H] exactly as the reference keeps it (un-transposed) moe.go:176 */
     NVL_T_MOE_OUT,         /* [E, H, I]                                                              */
+    /* Mamba2Layer (mamba2.go:9-27), as loadMamba2 leaves them (generic_loader.go:461-512: PyTorch layouts, NO transpose) */
+    NVL_T_MAMBA_IN_PROJ,   /* OUT_IN: [EH + conv_dim + heads, H]  InProj, used as MatMul(x, Transpose(InProj)) mamba2.go:90 */
+    NVL_T_MAMBA_CONV_W,    /* [conv_dim * K]  ConvWeight [conv_dim, 1, K] flattened                  */
+    NVL_T_MAMBA_CONV_B,    /* [conv_dim]                                                             */
+    NVL_T_MAMBA_A_LOG,     /* [heads]                                                                */
+    NVL_T_MAMBA_D,         /* [heads]                                                                */
+    NVL_T_MAMBA_DT_BIAS,   /* [heads]                                                                */
+    NVL_T_MAMBA_NORM,      /* [EH]                                                                   */
+    NVL_T_MAMBA_OUT_PROJ,  /* OUT_IN: [H, EH]  OutProj, MatMul(y, Transpose(OutProj))           mamba2.go:175 */
     NVL_T_COUNT
 } nvl_tensor_kind;
 
@@ -235,6 +249,9 @@ int nvl_get_hidden(nvl_model* m, int layer, float* out, int64_t n_floats);
 /* Debug/parity: copy a sequence's cache for one layer as the reference lays it out,
  * K and V each [nKV, T, hd] fp32 (kv_cache.go:5-6).  Returns T. */
 int nvl_get_kv(nvl_model* m, int64_t seq_id, int layer, float* k_out, float* v_out);
+/* Mamba2Layer.SSMState of a sequence's slot for a Mamba2 layer, [heads, head_dim, state] fp32 (mamba2.go:29-30; per
+ * SEQUENCE here, per layer in the reference).  Returns the number of floats, or < 0. */
+int nvl_get_mamba_state(nvl_model* m, int64_t seq_id, int layer, float* out);
 
 /* ---- runner: ModelRunner.Run semantics (nanovllm/model_runner.go:9-16) ---- */
 /* Replaces TensorModelRunner.Run (tensor_model_runner.go:55-97) for a scheduler batch:
@@ -295,6 +312,18 @@ typedef struct nvl_stats {
     uint64_t evictions;                   /* KV slots reclaimed from the least-recently-forwarded sequence by
                                              nvl_runner_run / _sampled when every slot was taken            */
 } nvl_stats;
+/* Per-launch-site view of the same events (nvl_set_profile on): one entry per (phase, site) that launched — QKV / O /
+ * FFN-up / FFN-down projections, attention, LM head, norms, MoE stages ... — with its launch count, summed device time
+ * and summed ALGORITHMIC work (flops, bytes: every weight byte once + operands in / results out; attention: every
+ * cached key and value once), so a caller can print achieved TFLOP/s or GB/s per kernel next to the roofline. */
+typedef struct nvl_kernel_stat {
+    int32_t  site;        /* name: nvl_kernel_site_name(site) */
+    int32_t  phase;       /* 0 = prefill passes (some sequence carried more than one token), 1 = decode passes */
+    uint64_t launches;
+    double   ms, flops, bytes;
+} nvl_kernel_stat;
+int nvl_get_kernel_stats(nvl_model* m, nvl_kernel_stat* out, int cap);   /* returns the number of entries (may exceed cap) */
+const char* nvl_kernel_site_name(int site);
 int nvl_set_profile(nvl_model* m, int per_kernel_events);
 int nvl_get_stats(nvl_model* m, nvl_stats* out);
 int nvl_reset_stats(nvl_model* m);

@@ -15,10 +15,13 @@ SLOTS = [
     "attn_norm_w", "attn_norm_b", "ffn_norm_w", "ffn_norm_b",
     "wq", "wk", "wv", "wkv", "wo", "bq", "bk", "bv", "bo",
     "w1", "b1", "w2", "b2", "router", "moe_in", "moe_out",
+    "mamba_in_proj", "mamba_conv_w", "mamba_conv_b", "mamba_a_log", "mamba_d", "mamba_dt_bias", "mamba_norm", "mamba_out_proj",
 ]
 SLOT_ID = {n: i for i, n in enumerate(SLOTS)}
 ONE_D = {"final_norm_w", "final_norm_b", "attn_norm_w", "attn_norm_b", "ffn_norm_w", "ffn_norm_b",
-         "bq", "bk", "bv", "bo", "b1", "b2"}
+         "bq", "bk", "bv", "bo", "b1", "b2",
+         "mamba_conv_w", "mamba_conv_b", "mamba_a_log", "mamba_d", "mamba_dt_bias", "mamba_norm"}
+OUT_IN_SLOTS = {"mamba_in_proj", "mamba_out_proj"}      # kept in the checkpoint's [out, in] layout by the reference's loader
 
 ATTN = {"mha": 0, "mqa": 1, "gqa": 2}
 NORM = {"layernorm": 0, "rmsnorm": 1}
@@ -52,6 +55,9 @@ class ModelConfigC(C.Structure):
         ("use_moe", C.c_int32), ("num_experts", C.c_int32), ("num_experts_per_tok", C.c_int32),
         ("embedding_multiplier", C.c_float), ("attention_multiplier", C.c_float),
         ("residual_multiplier", C.c_float), ("logits_scaling", C.c_float),
+        ("mamba_expand", C.c_int32), ("mamba_state_size", C.c_int32), ("mamba_num_heads", C.c_int32),
+        ("mamba_head_dim", C.c_int32), ("mamba_n_groups", C.c_int32), ("mamba_conv_kernel", C.c_int32),
+        ("mamba_layer_mask", C.c_uint64 * 2),
     ]
 
 
@@ -69,6 +75,11 @@ class StatsC(C.Structure):
                 ("attn_ms", C.c_double), ("attn_flops", C.c_double), ("attn_launches", C.c_uint64),
                 ("other_ms", C.c_double), ("other_launches", C.c_uint64), ("weight_bytes", C.c_double),
                 ("evictions", C.c_uint64)]
+
+
+class KernelStatC(C.Structure):         # nvl_kernel_stat
+    _fields_ = [("site", C.c_int32), ("phase", C.c_int32), ("launches", C.c_uint64), ("ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
 
 
 class SamplingParamsC(C.Structure):     # nvl_sampling_params == tensor.SamplingParams (sampling.go:10-15)
@@ -121,6 +132,7 @@ def lib():
     L.nvl_set_debug.argtypes = [vp, C.c_int]
     L.nvl_get_hidden.argtypes = [vp, C.c_int, vp, i64]
     L.nvl_get_kv.argtypes = [vp, i64, C.c_int, vp, vp]
+    L.nvl_get_mamba_state.argtypes = [vp, i64, C.c_int, vp]
     L.nvl_runner_run.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp]
     L.nvl_decode_sampled.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(SamplingParamsC), vp, vp, vp, vp]
     L.nvl_sample.argtypes = [vp, C.c_int, C.POINTER(SamplingParamsC), vp, vp, vp, vp]
@@ -129,6 +141,9 @@ def lib():
     L.nvl_set_profile.argtypes = [vp, C.c_int]
     L.nvl_get_stats.argtypes = [vp, C.POINTER(StatsC)]
     L.nvl_reset_stats.argtypes = [vp]
+    L.nvl_get_kernel_stats.argtypes = [vp, C.POINTER(KernelStatC), C.c_int]
+    L.nvl_kernel_site_name.argtypes = [C.c_int]
+    L.nvl_kernel_site_name.restype = C.c_char_p
     L.nvl_last_error.argtypes = [vp]
     L.nvl_last_error.restype = C.c_char_p
     L.nvl_op_matmul.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int]

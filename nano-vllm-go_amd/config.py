@@ -38,7 +38,21 @@ class ModelConfig:
     attention_multiplier: float = 0.0
     residual_multiplier: float = 0.0
     logits_scaling: float = 0.0
-    hybrid_layers: list = field(default_factory=list)
+    hybrid_layers: list = field(default_factory=list)     # config.go:113: "attention" | "mamba" | "mamba2" per layer
+    mamba_expand: int = 0             # config.go:100-106
+    mamba_state_size: int = 0
+    mamba_num_heads: int = 0
+    mamba_head_dim: int = 0
+    mamba_n_groups: int = 0
+    mamba_conv_kernel: int = 0
+
+    @property
+    def mamba_layer_mask(self):
+        m = [0, 0]
+        for i, t in enumerate(self.hybrid_layers[:128]):
+            if t in ("mamba", "mamba2"):
+                m[i >> 6] |= 1 << (i & 63)
+        return m
 
     def to_dict(self) -> dict:
         return asdict(self)
@@ -96,9 +110,27 @@ def _infer_config_from_json(raw: dict) -> ModelConfig:    # generic_loader.go:97
         return new_llama_config("7b")
     if mt == "granitemoe":
         return new_granite_moe_config("350m")
-    if mt == "granitemoehybrid":
-        raise NotImplementedError("Granite-4 hybrid (Mamba2) layers are outside the hot path (SURVEY.md §8 f-4)")
+    if mt == "granitemoehybrid":                        # :993-1001
+        hs = raw.get("hidden_size")
+        return new_granite_config("350m" if not isinstance(hs, (int, float)) or hs <= 800 else "1b")
     return new_gpt2_config()
+
+
+def new_granite_config(size: str = "350m") -> ModelConfig:   # config.go:241-330 (Granite-4 hybrid: attention + Mamba2)
+    c = ModelConfig(architecture="granite", attention_type="gqa", norm_type="rmsnorm", position_type="nope",
+                    activation_type="swiglu", block_style="sequential", rope_base=10000.0, norm_eps=1e-5, tied_embedding=True,
+                    mamba_expand=2, mamba_state_size=128, mamba_conv_kernel=4, mamba_num_heads=48)
+    if size == "1b":
+        c.model_name, c.vocab_size, c.hidden, c.num_layers, c.num_heads, c.num_kv_heads, c.head_dim, c.ffn_dim, \
+            c.max_seq_len = "granite-4.0-h-1b", 49152, 1536, 40, 12, 4, 128, 4096, 128000
+        c.mamba_n_groups = 8
+        c.hybrid_layers = ["mamba"] * 40
+    else:
+        c.model_name, c.vocab_size, c.hidden, c.num_layers, c.num_heads, c.num_kv_heads, c.head_dim, c.ffn_dim, \
+            c.max_seq_len = "granite-4.0-h-350m", 49152, 768, 32, 12, 4, 64, 2048, 32768
+        c.mamba_head_dim, c.mamba_n_groups = 32, 1
+        c.hybrid_layers = ["attention" if i in (10, 13, 17, 27) else "mamba" for i in range(32)]
+    return c
 
 
 def load_model_config(raw: dict | str) -> ModelConfig:
@@ -159,10 +191,19 @@ def load_model_config(raw: dict | str) -> ModelConfig:
         v = num(key)
         if v is not None:
             setattr(c, key, float(v))
+    if isinstance(raw.get("layer_types"), list):          # :917-925
+        c.hybrid_layers = [t if isinstance(t, str) else "" for t in raw["layer_types"]]
+    for key, attr in (("mamba_expand", "mamba_expand"), ("mamba_d_state", "mamba_state_size"), ("mamba_n_heads", "mamba_num_heads"),
+                      ("mamba_d_head", "mamba_head_dim"), ("mamba_n_groups", "mamba_n_groups"), ("mamba_d_conv", "mamba_conv_kernel")):
+        v = num(key)
+        if v is not None:
+            setattr(c, attr, int(v))
     v = num("num_local_experts")
     if v is not None:
         c.num_experts = int(v)
-        c.use_moe = True
+        # (reference: UseMoE = true for ANY value, 0 included; a hybrid checkpoint says 0 and runs the dense shared MLP —
+        # the device library treats 0 experts as "no MoE", and so does this mirror)
+        c.use_moe = v > 0
     v = num("num_experts_per_tok")
     if v is not None:
         c.num_experts_per_tok = int(v)

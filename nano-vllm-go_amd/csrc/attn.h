@@ -89,7 +89,12 @@ __global__ __launch_bounds__(512, HD == 64 ? 4 : 2) void attn_prefill_bf16_kerne
     constexpr int QROWS = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // NBUF x [K image | V image]
 
-    const int seq = blockIdx.z, kvh = blockIdx.y, qt = blockIdx.x;
+    // grid (kv head, query tile, sequence): consecutive block ids differ in the kv head, so with 8 | nKV every query tile of
+    // one (sequence, kv head) lands on the same XCD (ids that differ by 8 share one) and re-reads its K/V tiles from that
+    // XCD's L2 instead of from HBM / the memory-side cache
+    // Query tiles are taken LAST FIRST: under the causal mask tile qt walks qt+1 key-tile groups, so the longest workgroups
+    // of a sequence are dispatched first and the short ones fill the tail.
+    const int seq = blockIdx.z, kvh = blockIdx.x, qt = gridDim.y - 1 - blockIdx.y;
     const int S = p.seq_len[seq];
     const int R = S * p.group;                 // query rows of this (seq, kv head)
     if (qt * QROWS >= R) return;
@@ -202,13 +207,13 @@ __global__ __launch_bounds__(512, HD == 64 ? 4 : 2) void attn_prefill_bf16_kerne
         const bool whole = kt * 64 + 63 <= wave_first_limit;      // every row of the wave sees the whole tile
 #pragma unroll
         for (int qi = 0; qi < TQ; qi++) {
+            // scores stay RAW; the softmax scale (sl2 > 0: checked by the host) is folded into the exponent's fma:
+            // p = exp2(s * sl2 - m), m = running max of s * sl2
             float tmax = -INFINITY;
             if (whole) {
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    s[qi][t] *= sl2;
+                for (int t = 0; t < 4; t++)
                     tmax = fmaxf(tmax, fmaxf(fmaxf(s[qi][t][0], s[qi][t][1]), fmaxf(s[qi][t][2], s[qi][t][3])));
-                }
             } else {
                 bool ok;
                 const int lim = pos0 + row_of(qi, ok) / p.group - kt * 64 - fg * 4;   // last key (tile-relative) this row may see
@@ -216,21 +221,20 @@ __global__ __launch_bounds__(512, HD == 64 ? 4 : 2) void attn_prefill_bf16_kerne
                 for (int t = 0; t < 4; t++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        float v = s[qi][t][r] * sl2;
-                        v = (t * 16 + r <= lim) ? v : -INFINITY;     // reference: -1e10 then exp() == 0 exactly
+                        const float v = (t * 16 + r <= lim) ? s[qi][t][r] : -INFINITY;     // reference: -1e10 then exp() == 0 exactly
                         s[qi][t][r] = v;
                         tmax = fmaxf(tmax, v);
                     }
             }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run[qi], tmax);   // finite from the first tile on: key 0 <= limit
+            const float m_new = fmaxf(m_run[qi], tmax * sl2);   // finite from the first tile on: key 0 <= limit
             float psum = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float pv = __builtin_amdgcn_exp2f(s[qi][t][r] - m_new);
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[qi][t][r], sl2, -m_new));
                     s[qi][t][r] = pv;
                     psum += pv;
                 }

@@ -337,6 +337,32 @@ extern "C" int nvl_load_safetensors(nvl_model* m, const char* path) {
         up2d(m, NVL_T_TOK_EMB, 0, st.need("model.embed_tokens.weight"), IO);
         for (int l = 0; l < c.num_layers; l++) {
             const std::string p = "model.layers." + std::to_string(l);
+            const bool is_mamba = l < 128 && ((c.mamba_layer_mask[l >> 6] >> (l & 63)) & 1);
+            const bool hybrid = (c.mamba_layer_mask[0] | c.mamba_layer_mask[1]) != 0;
+            if (hybrid) {
+                // GetGraniteMapping (:145-181) + loadMamba2 (:461-512): Mamba2 tensors keep the checkpoint's layouts; every block
+                // of the hybrid has the shared MLP (shared_mlp.input_linear = gate | up already fused, output_linear)
+                if (is_mamba) {
+                    up2d(m, NVL_T_MAMBA_IN_PROJ, l, st.need(p + ".mamba.in_proj.weight"), OI);
+                    up2d(m, NVL_T_MAMBA_OUT_PROJ, l, st.need(p + ".mamba.out_proj.weight"), OI);
+                    up1d(m, NVL_T_MAMBA_CONV_W, l, st.need(p + ".mamba.conv1d.weight"));          // [conv_dim, 1, K]
+                    if (const StTensor* t = st.find(p + ".mamba.conv1d.bias")) up1d(m, NVL_T_MAMBA_CONV_B, l, *t);
+                    up1d(m, NVL_T_MAMBA_A_LOG, l, st.need(p + ".mamba.A_log"));
+                    up1d(m, NVL_T_MAMBA_D, l, st.need(p + ".mamba.D"));
+                    up1d(m, NVL_T_MAMBA_DT_BIAS, l, st.need(p + ".mamba.dt_bias"));
+                    up1d(m, NVL_T_MAMBA_NORM, l, st.need(p + ".mamba.norm.weight"));
+                } else {
+                    up2d(m, NVL_T_WQ, l, st.need(p + ".self_attn.q_proj.weight"), OI);
+                    up2d(m, NVL_T_WK, l, st.need(p + ".self_attn.k_proj.weight"), OI);
+                    up2d(m, NVL_T_WV, l, st.need(p + ".self_attn.v_proj.weight"), OI);
+                    up2d(m, NVL_T_WO, l, st.need(p + ".self_attn.o_proj.weight"), OI);
+                }
+                up2d(m, NVL_T_W1, l, st.need(p + ".shared_mlp.input_linear.weight"), OI);
+                up2d(m, NVL_T_W2, l, st.need(p + ".shared_mlp.output_linear.weight"), OI);
+                load_norm(m, st, p + ".input_layernorm.weight", NVL_T_ATTN_NORM_W, NVL_T_ATTN_NORM_B, l);
+                load_norm(m, st, p + ".post_attention_layernorm.weight", NVL_T_FFN_NORM_W, NVL_T_FFN_NORM_B, l);
+                continue;
+            }
             up2d(m, NVL_T_WQ, l, st.need(p + ".self_attn.q_proj.weight"), OI);
             up2d(m, NVL_T_WK, l, st.need(p + ".self_attn.k_proj.weight"), OI);
             up2d(m, NVL_T_WV, l, st.need(p + ".self_attn.v_proj.weight"), OI);
@@ -396,7 +422,7 @@ extern "C" int nvl_load_config_json(const char* path, nvl_model_config* out) {
             else if (mt == "falcon" || mt == "RefinedWeb" || mt == "RefinedWebModel") arch = "falcon";
             else if (mt == "llama" || mt == "LlamaForCausalLM") arch = "llama";
             else if (mt == "granitemoe") arch = "granitemoe";
-            else if (mt == "granitemoehybrid") throw std::runtime_error("granitemoehybrid (Mamba2 layers) is outside this library's scope");
+            else if (mt == "granitemoehybrid") arch = "granitehybrid";
             else arch = "gpt2";
         }
         c.rope_base = 10000.0; c.norm_eps = 1e-5f;
@@ -412,6 +438,19 @@ extern "C" int nvl_load_config_json(const char* path, nvl_model_config* out) {
             c.vocab_size = 32000; c.hidden = 4096; c.num_layers = 32; c.num_heads = 32; c.num_kv_heads = 8; c.head_dim = 128; c.ffn_dim = 11008;
             c.max_seq_len = 4096; c.attention_type = NVL_ATTN_GQA; c.norm_type = NVL_NORM_RMS; c.position_type = NVL_POS_ROPE;
             c.activation_type = NVL_ACT_SWIGLU; c.block_style = NVL_BLOCK_SEQUENTIAL; c.tied_embedding = 0; c.norm_eps = 1e-6f;
+        } else if (arch == "granitehybrid") {   // NewGraniteConfig (config.go:241-330): "350m" when hidden_size <= 800, else "1b" (:993-1001)
+            double hs = 768;
+            num("hidden_size", hs);
+            const bool small = hs <= 800;
+            c.vocab_size = 49152; c.hidden = small ? 768 : 1536; c.num_layers = small ? 32 : 40; c.num_heads = 12; c.num_kv_heads = 4;
+            c.head_dim = small ? 64 : 128; c.ffn_dim = small ? 2048 : 4096; c.max_seq_len = small ? 32768 : 128000;
+            c.attention_type = NVL_ATTN_GQA; c.norm_type = NVL_NORM_RMS; c.position_type = NVL_POS_NONE; c.activation_type = NVL_ACT_SWIGLU;
+            c.block_style = NVL_BLOCK_SEQUENTIAL; c.tied_embedding = 1; c.norm_eps = 1e-5f;
+            c.mamba_expand = 2; c.mamba_state_size = 128; c.mamba_conv_kernel = 4; c.mamba_num_heads = 48; c.mamba_head_dim = small ? 32 : 0;
+            c.mamba_n_groups = small ? 1 : 8;
+            const int nl = c.num_layers;
+            for (int i = 0; i < nl; i++) c.mamba_layer_mask[i >> 6] |= 1ull << (i & 63);
+            if (small) for (int a : {10, 13, 17, 27}) c.mamba_layer_mask[0] &= ~(1ull << a);      // template pattern, layer_types overrides
         } else {                         // NewGraniteMoEConfig("350m") (config.go:333-376); use_moe comes from num_local_experts
             c.vocab_size = 49155; c.hidden = 1024; c.num_layers = 24; c.num_heads = 16; c.num_kv_heads = 8; c.head_dim = 64; c.ffn_dim = 512;
             c.max_seq_len = 4096; c.attention_type = NVL_ATTN_GQA; c.norm_type = NVL_NORM_RMS; c.position_type = NVL_POS_ROPE;
@@ -445,7 +484,22 @@ extern "C" int nvl_load_config_json(const char* path, nvl_model_config* out) {
         if (num("attention_multiplier", v)) c.attention_multiplier = (float)v;
         if (num("residual_multiplier", v)) c.residual_multiplier = (float)v;
         if (num("logits_scaling", v)) c.logits_scaling = (float)v;
-        if (num("num_local_experts", v)) { c.num_experts = (int)v; c.use_moe = 1; }
+        // Granite hybrid fields (:917-946)
+        if (const JVal* lt = raw.get("layer_types")) if (lt->kind == JVal::ARR) {
+            c.mamba_layer_mask[0] = c.mamba_layer_mask[1] = 0;
+            for (size_t i = 0; i < lt->arr.size() && i < 128; i++)
+                if (lt->arr[i].kind == JVal::STR && (lt->arr[i].str == "mamba" || lt->arr[i].str == "mamba2"))
+                    c.mamba_layer_mask[i >> 6] |= 1ull << (i & 63);
+        }
+        if (num("mamba_expand", v)) c.mamba_expand = (int)v;
+        if (num("mamba_d_state", v)) c.mamba_state_size = (int)v;
+        if (num("mamba_n_heads", v)) c.mamba_num_heads = (int)v;
+        if (num("mamba_d_head", v)) c.mamba_head_dim = (int)v;
+        if (num("mamba_n_groups", v)) c.mamba_n_groups = (int)v;
+        if (num("mamba_d_conv", v)) c.mamba_conv_kernel = (int)v;
+        // (the reference sets UseMoE for ANY num_local_experts, 0 included; a hybrid checkpoint says 0 and its blocks
+        // run the dense shared MLP: 0 experts is treated as "no MoE" here)
+        if (num("num_local_experts", v)) { c.num_experts = (int)v; c.use_moe = v > 0 ? 1 : 0; }
         if (num("num_experts_per_tok", v)) c.num_experts_per_tok = (int)v;
         *out = c;
         return NVL_OK;

@@ -13,6 +13,7 @@
 #include "elem.h"
 #include "sample.h"
 #include "gemm.h"
+#include "mamba.h"
 
 namespace nvl {
 
@@ -28,11 +29,18 @@ struct LayerW {
     void* w_qkv = nullptr; int n_qkv = 0; float* b_qkv = nullptr;
     void* w1 = nullptr; int n1 = 0;      // fused rows (2F for SwiGLU, F for GELU)
     void* moe_in = nullptr;              // [E][2I (interleaved in bf16 mode)][H]
+    bool mamba = false;                  // a Mamba2 block (attention tensors absent); index among the Mamba2 layers
+    int mamba_idx = -1;
 };
 
 enum KClass { KC_GEMM = 0, KC_ATTN = 1, KC_OTHER = 2 };
+// where in the layer a launch sits (per-kernel roofline entries of nvl_get_kernel_stats; names in nvllm.hip)
+enum KSite { KS_OTHER = 0, KS_QKV, KS_ATTN, KS_OPROJ, KS_FFN_UP, KS_FFN_DOWN, KS_LM_HEAD, KS_NORM, KS_MOE_ROUTER, KS_MOE_PLAN,
+             KS_MOE_UP, KS_MOE_DOWN, KS_MOE_COMBINE, KS_EMBED, KS_ARGMAX, KS_ROPE, KS_MAMBA_IN, KS_MAMBA_CONV, KS_MAMBA_SCAN,
+             KS_MAMBA_GATE, KS_MAMBA_OUT, KS_ALLREDUCE, KS_COUNT };
 
-struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+struct ProfRec { hipEvent_t a, b; int cls; double flops; int site, phase; double bytes; };
+struct SiteStat { double ms = 0, flops = 0, bytes = 0; uint64_t launches = 0; };
 
 }  // namespace nvl
 
@@ -118,6 +126,10 @@ struct nvl_model {
     const int32_t* pending_slot_of = nullptr; const float* pending_gate_w = nullptr;   // MoE combine folded into the next norm
     // per-call metadata (one pinned host block mirrored on the device)
     int32_t* meta_host = nullptr; int32_t* meta_dev = nullptr; int64_t meta_ints = 0;
+    // Mamba2 (hybrid models): sizes, per-slot SSM state [slot][mamba layer][heads][hd][ss] fp32, workspaces
+    int n_mamba = 0, mEH = 0, mConv = 0, mP = 0, m_nh = 0, m_hd = 0, m_ss = 0, m_ng = 0, m_K = 0;
+    float* ssm_state = nullptr; int64_t ssm_layer_stride = 0, ssm_slot_stride = 0;
+    float *mproj = nullptr, *mxbc = nullptr, *mdelta = nullptr, *my = nullptr; void* myn = nullptr;
     SampleBufs samp;             // nvl_sample scratch
     int32_t* samp_hist = nullptr; int32_t* samp_hist_len = nullptr; int64_t samp_hist_cap = 0;   // nvl_decode_sampled: device-kept histories
     float* samp_u_steps = nullptr; int64_t samp_u_cap = 0;
@@ -127,6 +139,10 @@ struct nvl_model {
     bool keep_hidden = false; float* hidden = nullptr; int64_t hidden_tokens = 0; int hidden_last_M = 0;
     // stats
     nvl_stats stats{};
+    nvl::SiteStat site_stats[2][nvl::KS_COUNT];     // [phase: 0 prefill, 1 decode][site], filled when profiling
+    int site = 0, phase = 0;     // set by the forward pass just before a launch (consumed by KScope)
+    double kv_tok = 0;           // cached + new keys of the batch being enqueued (attention's algorithmic KV bytes)
+    double site_bytes = 0;       // algorithmic bytes of the next launch (0 = let the helper compute them)
     bool profile = false;
     std::vector<nvl::ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;

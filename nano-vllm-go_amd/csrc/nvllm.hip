@@ -72,7 +72,9 @@ bool is_1d(int kind) {
     switch (kind) {
         case NVL_T_FINAL_NORM_W: case NVL_T_FINAL_NORM_B: case NVL_T_ATTN_NORM_W: case NVL_T_ATTN_NORM_B:
         case NVL_T_FFN_NORM_W: case NVL_T_FFN_NORM_B: case NVL_T_BQ: case NVL_T_BK: case NVL_T_BV:
-        case NVL_T_BO: case NVL_T_B1: case NVL_T_B2: return true;
+        case NVL_T_BO: case NVL_T_B1: case NVL_T_B2:
+        case NVL_T_MAMBA_CONV_W: case NVL_T_MAMBA_CONV_B: case NVL_T_MAMBA_A_LOG: case NVL_T_MAMBA_D: case NVL_T_MAMBA_DT_BIAS:
+        case NVL_T_MAMBA_NORM: return true;
         default: return false;
     }
 }
@@ -92,11 +94,15 @@ hipEvent_t get_event(nvl_model* m) {
 }
 struct KScope {   // brackets ONE kernel launch with HIP events on the model's stream
     nvl_model* m; int cls; double flops; hipEvent_t a = nullptr, b = nullptr;
-    KScope(nvl_model* m_, int cls_, double flops_ = 0) : m(m_), cls(cls_), flops(flops_) {
+    int site, phase; double bytes;
+    KScope(nvl_model* m_, int cls_, double flops_ = 0, int site_ = -1, double bytes_ = -1) : m(m_), cls(cls_), flops(flops_) {
+        // the launch site and its algorithmic bytes: set by the caller (m->site / m->site_bytes) or passed here
+        site = site_ >= 0 ? site_ : m->site; bytes = bytes_ >= 0 ? bytes_ : m->site_bytes; phase = m->phase;
+        m->site = KS_OTHER; m->site_bytes = 0;
         if (m->profile) { a = get_event(m); b = get_event(m); NVL_HIP(hipEventRecord(a, m->stream)); }
     }
     ~KScope() {
-        if (m->profile && a) { (void)hipEventRecord(b, m->stream); m->prof.push_back({a, b, cls, flops}); }
+        if (m->profile && a) { (void)hipEventRecord(b, m->stream); m->prof.push_back({a, b, cls, flops, site, phase, bytes}); }
     }
 };
 void drain_profile(nvl_model* m) {
@@ -106,6 +112,8 @@ void drain_profile(nvl_model* m) {
         if (r.cls == KC_GEMM) { m->stats.gemm_ms += ms; m->stats.gemm_flops += r.flops; m->stats.gemm_launches++; }
         else if (r.cls == KC_ATTN) { m->stats.attn_ms += ms; m->stats.attn_flops += r.flops; m->stats.attn_launches++; }
         else { m->stats.other_ms += ms; m->stats.other_launches++; }
+        SiteStat& ss = m->site_stats[r.phase & 1][r.site >= 0 && r.site < KS_COUNT ? r.site : 0];
+        ss.ms += ms; ss.flops += r.flops; ss.bytes += r.bytes; ss.launches++;
         m->ev_pool.push_back(r.a); m->ev_pool.push_back(r.b);
     }
     m->prof.clear();
@@ -114,7 +122,10 @@ void drain_profile(nvl_model* m) {
 // ---- GEMM dispatch ---------------------------------------------------------------------------
 // out_f32: output element type of STORE (fp32 vs activation type)
 void gemm(nvl_model* m, int epi, bool out_f32, GemmArgs a, double flops = -1.0) {
-    KScope ks(m, KC_GEMM, flops >= 0 ? flops : 2.0 * (double)a.M * (double)a.N * (double)a.K);
+    // algorithmic bytes of a projection: every weight byte once + the activation operand + the output rows
+    const double gbytes = m->site_bytes > 0 ? m->site_bytes
+        : ((double)a.N * a.K + (double)a.M * a.K) * (double)m->wsize + (double)a.M * a.N * (out_f32 || epi == EPI_RESID ? 4.0 : (double)m->wsize);
+    KScope ks(m, KC_GEMM, flops >= 0 ? flops : 2.0 * (double)a.M * (double)a.N * (double)a.K, -1, gbytes);
     hipStream_t st = m->stream;
     if (m->f32) {
         switch (epi) {
@@ -173,6 +184,8 @@ extern "C" int nvl_create(const nvl_model_config* cfg, const nvl_runtime_opts* o
         return fail(nullptr, NVL_ERR_INVALID, "nvl_create: non-positive model dimension");
     if (c.head_dim != 64 && c.head_dim != 128)
         return fail(nullptr, NVL_ERR_INVALID, "nvl_create: head_dim must be 64 or 128");
+    if (c.attention_multiplier < 0.f)      // the kernels take the row maximum before scaling
+        return fail(nullptr, NVL_ERR_INVALID, "nvl_create: attention_multiplier must not be negative");
     if (c.hidden % 64 != 0 || (c.ffn_dim % 64) != 0)
         return fail(nullptr, NVL_ERR_INVALID, "nvl_create: hidden and ffn_dim must be multiples of 64");
     // runtime options are validated BEFORE any size is derived from them (a zero-valued host struct must not turn into
@@ -194,6 +207,23 @@ extern "C" int nvl_create(const nvl_model_config* cfg, const nvl_runtime_opts* o
     if (opts->device < 0 || nvl_device_count() <= opts->device)
         return fail(nullptr, NVL_ERR_NO_DEVICE,
                     "nvl_create: no HIP device (this library has no CPU fallback)");
+    const bool any_mamba = (c.mamba_layer_mask[0] | c.mamba_layer_mask[1]) != 0;
+    if (any_mamba) {
+        const int eh = c.mamba_expand * c.hidden;
+        const int mhd = c.mamba_head_dim > 0 ? c.mamba_head_dim : (c.mamba_num_heads > 0 ? eh / c.mamba_num_heads : 0);
+        if (c.num_layers > 128 || c.mamba_expand <= 0 || c.mamba_state_size <= 0 || c.mamba_num_heads <= 0 || c.mamba_n_groups <= 0 ||
+            c.mamba_conv_kernel <= 0 || c.mamba_conv_kernel > 8 || mhd <= 0 || mhd * c.mamba_num_heads != eh)
+            return fail(nullptr, NVL_ERR_INVALID, "nvl_create: bad Mamba2 dimensions (heads x head_dim must equal expand x hidden)");
+        // the scan kernel keeps state_size / (256 / head_dim) states per thread: head_dim | 256, at most 32 states per thread
+        if (256 % mhd != 0 || 256 / mhd > 64 || c.mamba_state_size % (256 / mhd) != 0 || c.mamba_state_size / (256 / mhd) > 32 ||
+            (c.mamba_state_size / (256 / mhd)) % 4 != 0 || eh % 64 != 0 || c.mamba_num_heads % c.mamba_n_groups != 0)
+            return fail(nullptr, NVL_ERR_INVALID, "nvl_create: Mamba2 head_dim / state_size not supported by the scan kernel");
+        if (tp > 1) return fail(nullptr, NVL_ERR_INVALID, "nvl_create: tensor parallelism does not cover Mamba2 layers");
+        if (opts->kv_num_blocks > 0)
+            return fail(nullptr, NVL_ERR_INVALID, "nvl_create: Mamba2 layers keep per-sequence state in KV slots: not available in paged-KV mode");
+        if (c.use_moe || c.block_style != NVL_BLOCK_SEQUENTIAL)
+            return fail(nullptr, NVL_ERR_INVALID, "nvl_create: hybrid (Mamba2) models are sequential blocks with a dense MLP");
+    }
     nvl_model* m = new (std::nothrow) nvl_model();
     if (!m) return fail(nullptr, NVL_ERR_OOM, "nvl_create: out of host memory");
     NVL_TRY(m)
@@ -234,6 +264,13 @@ extern "C" int nvl_create(const nvl_model_config* cfg, const nvl_runtime_opts* o
     else m->attn_scale = 1.0f / std::sqrt((float)m->hd);
     m->resid_alpha = c.residual_multiplier != 0.f ? c.residual_multiplier : 1.0f;
     m->layers.resize(m->L);
+    for (int li = 0; li < m->L && li < 128; li++)
+        if ((c.mamba_layer_mask[li >> 6] >> (li & 63)) & 1) { m->layers[li].mamba = true; m->layers[li].mamba_idx = m->n_mamba++; }
+    if (m->n_mamba) {
+        m->mEH = c.mamba_expand * c.hidden; m->m_nh = c.mamba_num_heads; m->m_ss = c.mamba_state_size; m->m_ng = c.mamba_n_groups;
+        m->m_K = c.mamba_conv_kernel; m->m_hd = c.mamba_head_dim > 0 ? c.mamba_head_dim : m->mEH / m->m_nh;
+        m->mConv = m->mEH + 2 * m->m_ng * m->m_ss; m->mP = m->mEH + m->mConv + m->m_nh;
+    }
     if (m->opts.max_batch_tokens <= 0) m->opts.max_batch_tokens = c.max_seq_len;
     *out = m;
     return NVL_OK;
@@ -263,6 +300,7 @@ extern "C" void nvl_destroy(nvl_model* m) {
     dfree(m->xn_last); dfree(m->logits); dfree(m->argmax_dev); dfree(m->argmax_pval); dfree(m->argmax_pidx); dfree(m->router_logits); dfree(m->expert_ids);
     dfree(m->expert_w); dfree(m->seg_start); dfree(m->moe_counts); dfree(m->moe_cursor); dfree(m->moe_tile_map); dfree(m->moe_n_mtiles); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo); dfree(m->moe_xg);
     dfree(m->meta_dev); dfree(m->hidden); dfree(m->sk_part); dfree(m->tp_part); dfree(m->ring); dfree(m->rs_part);
+    dfree(m->ssm_state); dfree(m->mproj); dfree(m->mxbc); dfree(m->mdelta); dfree(m->my); dfree(m->myn);
     free_sample_bufs(m->samp);
     dfree(m->samp_hist); dfree(m->samp_hist_len); dfree(m->samp_u_steps);
     if (m->tp_comm) (void)ncclCommDestroy((ncclComm_t)m->tp_comm);
@@ -338,6 +376,8 @@ int64_t full_out(const nvl_model* m, int kind) {
         case NVL_T_W1: return m->cfg.activation_type == NVL_ACT_SWIGLU ? 2 * (int64_t)m->F_full : m->F_full;
         case NVL_T_W2: return m->H;
         case NVL_T_ROUTER: return m->cfg.num_experts;
+        case NVL_T_MAMBA_IN_PROJ: return m->mP;
+        case NVL_T_MAMBA_OUT_PROJ: return m->H;
         default: return -1;
     }
 }
@@ -345,6 +385,7 @@ int64_t full_in(const nvl_model* m, int kind) {
     switch (kind) {
         case NVL_T_WO: return (int64_t)m->nH_full * m->hd;
         case NVL_T_W2: return m->F_full;
+        case NVL_T_MAMBA_OUT_PROJ: return m->mEH;
         default: return m->H;
     }
 }
@@ -370,6 +411,11 @@ extern "C" int nvl_upload_tensor(nvl_model* m, int kind, int layer, const void* 
             if (kind == NVL_T_BQ) want = (int64_t)m->nH_full * m->hd;
             else if (kind == NVL_T_BK || kind == NVL_T_BV) want = (int64_t)m->nKV_full * m->hd;
             else if (kind == NVL_T_B1) want = m->F_full;
+            else if (kind == NVL_T_MAMBA_CONV_W) want = (int64_t)m->mConv * m->m_K;
+            else if (kind == NVL_T_MAMBA_CONV_B) want = m->mConv;
+            else if (kind == NVL_T_MAMBA_A_LOG || kind == NVL_T_MAMBA_D || kind == NVL_T_MAMBA_DT_BIAS) want = m->m_nh;
+            else if (kind == NVL_T_MAMBA_NORM) want = m->mEH;
+            if (kind >= NVL_T_MAMBA_IN_PROJ && !m->n_mamba) return fail(m, NVL_ERR_INVALID, "nvl_upload_tensor: the model has no Mamba2 layers");
             if (rows <= 0 || n != want) {
                 snprintf(buf, sizeof buf, "1-D tensor kind %d has %lld elements, the model needs %lld", kind, (long long)n,
                          (long long)want);
@@ -408,6 +454,7 @@ extern "C" int nvl_upload_tensor(nvl_model* m, int kind, int layer, const void* 
         upload_2d(m, t, data, dtype, rows, cols, false, Slice2D{rows, cols, 0, 0, 0}, rows, true);
         return NVL_OK;
     }
+    if (kind >= NVL_T_MAMBA_IN_PROJ && !m->n_mamba) return fail(m, NVL_ERR_INVALID, "nvl_upload_tensor: the model has no Mamba2 layers");
     const int64_t SN = full_out(m, kind), SK = full_in(m, kind);
     if (SN < 0) return fail(m, NVL_ERR_INVALID, "nvl_upload_tensor: kind is not a 2-D weight");
     const int64_t got_in = layout == NVL_LAYOUT_IN_OUT ? rows : cols;
@@ -548,6 +595,24 @@ extern "C" int nvl_finalize(nvl_model* m) {
     for (int li = 0; li < m->L; li++) {
         LayerW& l = m->layers[li];
         need(l.t[NVL_T_ATTN_NORM_W].present(), "attention/input norm weight");
+        if (l.mamba) {       // Mamba2 block: in/out projections + SSM parameters, then the shared MLP (loadMamba2 + loadFFN)
+            need(l.t[NVL_T_MAMBA_IN_PROJ].present() && l.t[NVL_T_MAMBA_OUT_PROJ].present() && l.t[NVL_T_MAMBA_CONV_W].present(),
+                 "Mamba2 in_proj / out_proj / conv1d weight");
+            need(l.t[NVL_T_FFN_NORM_W].present() && l.t[NVL_T_W1].present() && l.t[NVL_T_W2].present(), "Mamba2 block: FFN norm / shared MLP");
+            const bool swiglu = c.activation_type == NVL_ACT_SWIGLU;
+            l.n1 = swiglu ? 2 * m->F : m->F;
+            if (swiglu && !m->f32) {
+                auto idx = swiglu_interleave(m->F, 0);
+                const int64_t np = round_up(l.n1, W_ROW_PAD);
+                idx.resize((size_t)np, -1);
+                l.w1 = dmalloc_bytes(np * H * (int64_t)m->wsize);
+                gather_rows(m, l.t[NVL_T_W1].p, idx, l.w1, H);
+                dfree(l.t[NVL_T_W1].p); l.t[NVL_T_W1].p = nullptr;
+            } else {
+                l.w1 = l.t[NVL_T_W1].p; l.t[NVL_T_W1].p = nullptr;
+            }
+            continue;
+        }
         need(l.t[NVL_T_WQ].present() && l.t[NVL_T_WO].present(), "attention Q/O projection");
         const bool mqa = c.attention_type == NVL_ATTN_MQA;
         if (mqa) need(l.t[NVL_T_WKV].present(), "MQA fused KV projection");
@@ -685,6 +750,18 @@ extern "C" int nvl_finalize(nvl_model* m) {
         m->slot_of = dmalloc<int32_t>(Mmax * k);
         m->moe_eo = dmalloc<float>(Mmax * k * H);
         if (!m->f32) m->moe_xg = dmalloc_bytes(round_up(Mmax * k, 64) * H * 2);
+    }
+    if (m->n_mamba) {
+        m->ssm_layer_stride = (int64_t)m->m_nh * m->m_hd * m->m_ss;
+        m->ssm_slot_stride = m->ssm_layer_stride * m->n_mamba;
+        m->ssm_state = dmalloc<float>(m->ssm_slot_stride * S);
+        NVL_HIP(hipMemsetAsync(m->ssm_state, 0, (size_t)(m->ssm_slot_stride * S) * 4, m->stream));
+        m->mproj = dmalloc<float>(Mmax * m->mP);
+        m->mxbc = dmalloc<float>(Mmax * m->mConv);
+        m->mdelta = dmalloc<float>(Mmax * m->m_nh);
+        m->my = dmalloc<float>(Mmax * m->mEH);
+        m->myn = dmalloc_bytes(Mp * m->mEH * (int64_t)m->wsize);
+        NVL_HIP(hipMemsetAsync(m->myn, 0, (size_t)(Mp * m->mEH) * m->wsize, m->stream));
     }
     if (!m->f32) m->sk_part = dmalloc<float>((int64_t)m->sk_max_slices * 64 * H);
     if (!m->f32) m->rs_part = dmalloc<float>((int64_t)cdiv(H, 16) * DEFER_MAX_M);
@@ -835,7 +912,7 @@ static int g_norm_t16 = 1;     // nvl_set_tuning key 9: norm_tile16_kernel for p
 template <typename ActT>
 void launch_norm(nvl_model* m, float* x, const int32_t* rows_idx, const float* w, const float* b,
                  void* y, int rows) {
-    KScope ks(m, KC_OTHER);
+    KScope ks(m, KC_OTHER, 0, KS_NORM, (double)rows * m->H * (4.0 + (double)m->wsize));
     PendingResid pr{nullptr, 0, 0, 0.f, nullptr, nullptr};
     if (m->pending_slices > 0) {            // complete the residual add the previous decode GEMM left as split-K slices
         pr.part = m->pending_part; pr.slices = m->pending_slices; pr.rows_total = m->pending_rows; pr.alpha = m->pending_alpha;
@@ -878,7 +955,9 @@ void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, do
     a.seq_tok_start = md.seq_tok_start; a.seq_len = md.seq_len; a.seq_pos = md.seq_pos; a.blk_table = md.blk_table; a.tbl_stride = m->blocks_per_seq;
     a.bs_shift = (m->Tmax & (m->Tmax - 1)) == 0 ? __builtin_ctz((unsigned)m->Tmax) : -1;
     a.nH = m->nH; a.nKV = m->nKV; a.group = m->group; a.scale = m->attn_scale;
-    KScope ks(m, KC_ATTN, flops);
+    // algorithmic bytes: every cached key/value of the batch once + Q in + O out (+ the fp32 QKV row of a fused decode step)
+    const double abytes = m->kv_tok * 2.0 * m->nKV * m->hd * (double)m->wsize;
+    KScope ks(m, KC_ATTN, flops, KS_ATTN, abytes);
     if (m->f32) {
         const size_t lds = (size_t)m->Tmax * 4;
         hipLaunchKernelGGL(attn_f32_kernel, dim3(max_len, m->nH, n_seqs), dim3(256), lds, m->stream, a, m->hd);
@@ -913,7 +992,7 @@ void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, do
     } else {
         // 256 query rows (position x head-in-group, position-major) per workgroup of 8 waves; K/V tiles by LDS-DMA
         const int64_t qrows = (int64_t)max_len * m->group;
-        dim3 grid(cdiv(qrows, 256), m->nKV, n_seqs);
+        dim3 grid(m->nKV, cdiv(qrows, 256), n_seqs);      // (kv head fastest: attn.h)
         if (m->hd == 64) {
             hipLaunchKernelGGL((attn_prefill_bf16_kernel<64>), grid, dim3(512), attn_prefill_lds_bytes<64>(), m->stream, a);
         } else {
@@ -925,7 +1004,7 @@ void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, do
 }
 
 void rope_kv(nvl_model* m, int li, const Meta& md, int M) {
-    KScope ks(m, KC_OTHER);
+    KScope ks(m, KC_OTHER, 0, KS_ROPE, (double)M * m->n_qkv * (4.0 + (double)m->wsize));
     dim3 grid(M, m->nH + 2 * m->nKV);
     const int thr = m->hd / 2;
     void* kc = (char*)m->kcache + (size_t)li * m->layer_stride * m->wsize;
@@ -963,7 +1042,7 @@ GemmArgs mk(const void* A, int lda, const void* W, void* C, int ldc, const float
 // process form a local group (nvl_tp_attach_local) and are driven from one host thread each; the last
 // thread to arrive sums every member's buffer on the device and hands the result back to all of them.
 void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
-    KScope ks(m, KC_OTHER);
+    KScope ks(m, KC_OTHER, 0, KS_ALLREDUCE, (double)count * 4.0);
     if (m->tp_comm) {
         const ncclResult_t rc = ncclAllReduce(buf, buf, (size_t)count, ncclFloat, ncclSum, (ncclComm_t)m->tp_comm, m->stream);
         if (rc != ncclSuccess) throw std::runtime_error(std::string("ncclAllReduce: ") + ncclGetErrorString(rc));
@@ -1060,6 +1139,7 @@ void ffn_up(nvl_model* m, const LayerW& l, int M, bool deferred_norm = false) {
     const float* b1 = (const float*)l.t[NVL_T_B1].p;
     if (swiglu) {
         if (m->f32) {
+            m->site = KS_FFN_UP;
             gemm(m, EPI_STORE, true, mk(m->xn, m->H, l.w1, m->h2, 2 * m->F, nullptr, 1.f, M, 2 * m->F, m->H));
             KScope ks(m, KC_OTHER);
             const int64_t n = (int64_t)M * m->F;
@@ -1069,9 +1149,11 @@ void ffn_up(nvl_model* m, const LayerW& l, int M, bool deferred_norm = false) {
         } else {
             GemmArgs a = mk(m->xn, m->H, l.w1, m->hbuf, m->F, nullptr, 1.f, M, 2 * m->F, m->H);
             if (deferred_norm) set_deferred_in(m, a);
+            m->site = KS_FFN_UP;
             gemm(m, EPI_SWIGLU, false, a);
         }
     } else {
+        m->site = KS_FFN_UP;
         gemm(m, EPI_GELU, false, mk(m->xn, m->H, l.w1, m->hbuf, m->F, b1, 1.f, M, m->F, m->H));
     }
 }
@@ -1084,6 +1166,9 @@ void moe(nvl_model* m, const LayerW& l, int M) {
     const nvl_model_config& c = m->cfg;
     const int E = c.num_experts, k = c.num_experts_per_tok, I = m->F, H = m->H;
     const int pairs = M * k;
+    // algorithmic weight bytes of the expert GEMMs: the experts a batch of `pairs` (token, rank) pairs can touch, once
+    const double e_touch = (double)std::min(E, pairs);
+    m->site = KS_MOE_ROUTER;
     gemm(m, EPI_STORE, true, mk(m->xn, H, l.t[NVL_T_ROUTER].p, m->router_logits, 128, nullptr, 1.f, M, E, H));
     // decode-sized batches: one planning launch, and the weighted combine rides on the norm that follows
     const bool small = !m->f32 && M <= 64 && pairs <= MOE_PLAN_MAX_PAIRS && E <= MOE_PLAN_MAX_E && g_moe_small;
@@ -1091,12 +1176,12 @@ void moe(nvl_model* m, const LayerW& l, int M) {
     // 4096 rows per expert: 441 K vs 450 K prefill tok/s)
     const int BM = (!m->f32 && !small && g_moe_bm == 256) ? 256 : 128;
     if (small) {
-        KScope ks(m, KC_OTHER);
+        KScope ks(m, KC_OTHER, 0, KS_MOE_PLAN);
         hipLaunchKernelGGL(moe_plan_kernel, dim3(1), dim3(M <= 4 ? 256 : (M <= 8 ? 512 : 1024)), 0, m->stream, m->router_logits, 128, M, E, k, 128, m->expert_ids,
                            m->expert_w, m->seg_start, m->moe_tile_map, m->moe_n_mtiles, m->perm_token, m->slot_of);
         NVL_HIP(hipGetLastError());
     } else {
-        KScope ks(m, KC_OTHER);
+        KScope ks(m, KC_OTHER, 0, KS_MOE_PLAN);
         NVL_HIP(hipMemsetAsync(m->moe_counts, 0, (size_t)E * 4, m->stream));
         hipLaunchKernelGGL(moe_route_kernel, dim3(cdiv(M, 4)), dim3(256), 0, m->stream, m->router_logits, 128, M, E, k,
                            m->expert_ids, m->expert_w);
@@ -1142,9 +1227,11 @@ void moe(nvl_model* m, const LayerW& l, int M) {
             a.A = m->moe_xg; a.a_rows = nullptr;
         }
         a.w_expert_stride = (int64_t)2 * I * H; a.grp_bm = BM; a.grp_deep = small && g_moe_deep;
+        m->site = KS_MOE_UP; m->site_bytes = (e_touch * 2 * I * H + (double)pairs * H + (double)pairs * I) * (double)m->wsize;
         gemm(m, EPI_SWIGLU, false, a, 2.0 * pairs * 2 * I * H);
         GemmArgs d = mk(m->hbuf, I, l.t[NVL_T_MOE_OUT].p, m->moe_eo, H, nullptr, 1.f, max_mtiles, H, I);
         d.tile_map = m->moe_tile_map; d.n_mtiles = m->moe_n_mtiles; d.w_expert_stride = (int64_t)H * I; d.grp_bm = BM; d.grp_deep = small && g_moe_deep;
+        m->site = KS_MOE_DOWN; m->site_bytes = (e_touch * H * I + (double)pairs * I) * (double)m->wsize + (double)pairs * H * 4.0;
         gemm(m, EPI_STORE, true, d, 2.0 * pairs * H * I);
     }
     if (small && !m->keep_hidden && m->pending_slices == 0 && H % 4 == 0 && H <= 1024 * NORM_ROW_MAXCH) {
@@ -1152,7 +1239,7 @@ void moe(nvl_model* m, const LayerW& l, int M) {
         m->pending_part = m->moe_eo; m->pending_slices = k; m->pending_rows = M; m->pending_alpha = c.residual_multiplier;
         m->pending_slot_of = m->slot_of; m->pending_gate_w = m->expert_w;
     } else {
-        KScope ks(m, KC_OTHER);
+        KScope ks(m, KC_OTHER, 0, KS_MOE_COMBINE, (double)pairs * H * 4.0 + (double)M * H * 8.0);
         hipLaunchKernelGGL(moe_combine_kernel, dim3(M), dim3(256), 0, m->stream, m->moe_eo, m->slot_of, m->expert_w, k,
                            c.residual_multiplier, m->x, H, 1);
         NVL_HIP(hipGetLastError());
@@ -1172,6 +1259,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
     const nvl_model_config& c = m->cfg;
     const int H = m->H;
     m->pending_slices = 0;
+    m->phase = max_len > 1 ? 0 : 1;         // per-site profile: prefill / decode
     if (m->keep_hidden && m->hidden_tokens < M) {
         dfree(m->hidden);
         m->hidden = dmalloc<float>((int64_t)m->L * M * H);
@@ -1181,7 +1269,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
 
     // ---- embed (generic_model.go:295-302) -------------------------------------------------
     if (!(seam & 1)) {
-        KScope ks(m, KC_OTHER);
+        KScope ks(m, KC_OTHER, 0, KS_EMBED, (double)M * H * (4.0 + (double)m->wsize));
         const void* pe = (c.position_type == NVL_POS_LEARNED) ? m->g[NVL_T_POS_EMB].p : nullptr;
         const int pe_rows = pe ? (int)std::min<int64_t>(m->g[NVL_T_POS_EMB].rows, c.max_seq_len) : 0;
         if (m->f32)
@@ -1201,11 +1289,58 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
     const bool big_decode = max_len == 1 && M <= g_chunk_max_m && m->group <= 16 && g_force_tile == 0;
     const bool defer_ok = g_defer_norm && !m->f32 && (M <= 64 || (M <= DEFER_MAX_M && big_decode && g_defer_norm == 1)) && !c.use_moe && m->tp == 1 && !m->tp_force && !m->keep_hidden &&
                           c.block_style == NVL_BLOCK_SEQUENTIAL && c.norm_type == NVL_NORM_RMS &&
-                          c.activation_type == NVL_ACT_SWIGLU && H % 256 == 0 && m->rs_part;
+                          c.activation_type == NVL_ACT_SWIGLU && H % 256 == 0 && m->rs_part && m->n_mamba == 0;
     const bool all_rows = (flags & NVL_FWD_ALL_LOGITS) != 0;
     bool xn_deferred = false;       // m->xn holds xn_raw of the upcoming norm, m->rs_part its x^2 partials
     for (int li = 0; li < m->L; li++) {
         const LayerW& l = m->layers[li];
+        if (l.mamba) {
+            // forwardMamba2 (generic_model.go:160-202): norm, Mamba2Layer.Forward (mamba2.go:74-181), residual; norm, shared MLP, residual
+            norm(m, m->x, nullptr, l.t[NVL_T_ATTN_NORM_W], l.t[NVL_T_ATTN_NORM_B], m->xn, M);
+            m->site = KS_MAMBA_IN;
+            gemm(m, EPI_STORE, true, mk(m->xn, H, l.t[NVL_T_MAMBA_IN_PROJ].p, m->mproj, m->mP, nullptr, 1.f, M, m->mP, H));
+            MambaArgs a{};
+            a.proj = m->mproj; a.P = m->mP; a.EH = m->mEH; a.conv_dim = m->mConv; a.nh = m->m_nh; a.hd = m->m_hd; a.ss = m->m_ss;
+            a.ng = m->m_ng; a.K = m->m_K;
+            a.conv_w = (const float*)l.t[NVL_T_MAMBA_CONV_W].p; a.conv_b = (const float*)l.t[NVL_T_MAMBA_CONV_B].p;
+            a.a_log = (const float*)l.t[NVL_T_MAMBA_A_LOG].p; a.Dskip = (const float*)l.t[NVL_T_MAMBA_D].p;
+            a.dt_bias = (const float*)l.t[NVL_T_MAMBA_DT_BIAS].p; a.norm_w = (const float*)l.t[NVL_T_MAMBA_NORM].p;
+            a.xbc = m->mxbc; a.delta = m->mdelta; a.y = m->my;
+            a.state = m->ssm_state + (int64_t)l.mamba_idx * m->ssm_layer_stride; a.state_slot_stride = m->ssm_slot_stride;
+            a.tok_pos = md.tok_pos; a.tok_seq = md.tok_tbl; a.seq_tok_start = md.seq_tok_start; a.seq_len = md.seq_len;
+            a.seq_pos = md.seq_pos; a.seq_slot = md.blk_table;     // slab mode: token -> sequence index i, blk_table[i] = slot
+            {
+                KScope ks(m, KC_OTHER, 0, KS_MAMBA_CONV, (double)M * (m->mP + m->mConv + m->m_nh) * 4.0);
+                hipLaunchKernelGGL(mamba_conv_kernel, dim3(M), dim3(256), 0, m->stream, a);
+                NVL_HIP(hipGetLastError());
+            }
+            {
+                KScope ks(m, KC_OTHER, 2.0 * 3.0 * (double)M * m->mEH * m->m_ss, KS_MAMBA_SCAN,
+                          (double)M * (m->mConv + m->m_nh + m->mEH) * 4.0 + 2.0 * n_seqs * (double)m->ssm_layer_stride * 4.0);
+                const int per = m->m_ss / (256 / m->m_hd);
+                dim3 grid(m->m_nh, n_seqs);
+                if (per <= 4) hipLaunchKernelGGL(mamba_scan_kernel<4>, grid, dim3(256), 0, m->stream, a);
+                else if (per <= 8) hipLaunchKernelGGL(mamba_scan_kernel<8>, grid, dim3(256), 0, m->stream, a);
+                else if (per <= 16) hipLaunchKernelGGL(mamba_scan_kernel<16>, grid, dim3(256), 0, m->stream, a);
+                else hipLaunchKernelGGL(mamba_scan_kernel<32>, grid, dim3(256), 0, m->stream, a);
+                NVL_HIP(hipGetLastError());
+            }
+            {
+                KScope ks(m, KC_OTHER, 0, KS_MAMBA_GATE, (double)M * m->mEH * (8.0 + (double)m->wsize));
+                if (m->f32) hipLaunchKernelGGL((mamba_gate_norm_kernel<float>), dim3(M), dim3(256), 0, m->stream, a, (float*)m->myn);
+                else hipLaunchKernelGGL((mamba_gate_norm_kernel<bf16_t>), dim3(M), dim3(256), 0, m->stream, a, (bf16_t*)m->myn);
+                NVL_HIP(hipGetLastError());
+            }
+            m->site = KS_MAMBA_OUT;
+            resid_gemm(m, m->myn, m->mEH, l.t[NVL_T_MAMBA_OUT_PROJ].p, nullptr, m->resid_alpha, M, H, m->mEH);
+            norm(m, m->x, nullptr, l.t[NVL_T_FFN_NORM_W], l.t[NVL_T_FFN_NORM_B], m->xn, M);
+            ffn_up(m, l, M);
+            m->site = KS_FFN_DOWN;
+            resid_gemm(m, m->hbuf, m->F, l.t[NVL_T_W2].p, (const float*)l.t[NVL_T_B2].p, m->resid_alpha, M, H, m->F);
+            if (m->keep_hidden)
+                NVL_HIP(hipMemcpyAsync(m->hidden + (int64_t)li * M * H, m->x, (size_t)M * H * 4, hipMemcpyDeviceToDevice, m->stream));
+            continue;
+        }
         const bool qkv_deferred = xn_deferred;
         if (!xn_deferred && !(li == 0 && (seam & 1)))
             norm(m, m->x, nullptr, l.t[NVL_T_ATTN_NORM_W], l.t[NVL_T_ATTN_NORM_B], m->xn, M);
@@ -1224,10 +1359,12 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
             a.qkv.kcache = (bf16_t*)m->kcache + (int64_t)li * m->layer_stride;
             a.qkv.vcache = (bf16_t*)m->vcache + (int64_t)li * m->layer_stride;
             a.qkv.slot_stride = m->slot_stride; a.qkv.Tmax = m->Tmax; a.qkv.nH = m->nH; a.qkv.nKV = m->nKV; a.qkv.hd = m->hd;
+            m->site = KS_QKV;
             gemm(m, EPI_QKV, false, a);
         } else {
             GemmArgs aq = mk(m->xn, H, l.w_qkv, m->qkv, m->n_qkv, l.b_qkv, 1.f, M, m->n_qkv, H);
             if (qkv_deferred) set_deferred_in(m, aq);
+            m->site = KS_QKV;
             gemm(m, EPI_STORE, true, aq);
             fused_dec = !m->f32 && max_len == 1 && m->group <= 16;     // decode: RoPE + KV append live in the attention kernel
             if (!fused_dec) rope_kv(m, li, md, M);
@@ -1238,12 +1375,15 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
             // generic_model.go:395-418: r + [am*]attn + [rm*]ffn, both branches read the same normed x
             const bool mults = c.attention_multiplier != 0.f && c.residual_multiplier != 0.f;
             ffn_up(m, l, M);
+            m->site = KS_OPROJ;
             resid_gemm(m, m->attn_out, qw, l.t[NVL_T_WO].p, bo, mults ? c.attention_multiplier : 1.f, M, H, qw);
+            m->site = KS_FFN_DOWN;
             resid_gemm(m, m->hbuf, m->F, l.t[NVL_T_W2].p, (const float*)l.t[NVL_T_B2].p, mults ? c.residual_multiplier : 1.f,
                        M, H, m->F);   // (only one of the two may be pending: the second one adds into x directly)
         } else {
             // decode, RMSNorm + SwiGLU: the O-projection carries the FFN norm (deferred RMSNorm, gemm.h) — one launch less
             const bool defer = defer_ok && m->pending_slices == 0 && !l.t[NVL_T_FFN_NORM_B].present();
+            m->site = KS_OPROJ;
             if (defer) {
                 resid_gemm(m, m->attn_out, qw, l.t[NVL_T_WO].p, bo, m->resid_alpha, M, H, qw, (const float*)l.t[NVL_T_FFN_NORM_W].p);
             } else {
@@ -1260,6 +1400,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
                 const DevTensor* nxt_b = li + 1 < m->L ? &m->layers[li + 1].t[NVL_T_ATTN_NORM_B] : &m->g[NVL_T_FINAL_NORM_B];
                 const bool defer2 = defer_ok && g_defer_norm != 3 && m->pending_slices == 0 && !nxt_b->present() &&
                                     (li + 1 < m->L || (!all_rows && M == n_seqs && M <= 64));   // (the LM head of a larger batch runs on the tile kernels)
+                m->site = KS_FFN_DOWN;
                 resid_gemm(m, m->hbuf, m->F, l.t[NVL_T_W2].p, (const float*)l.t[NVL_T_B2].p, m->resid_alpha, M, H, m->F,
                            defer2 ? (const float*)nxt_w->p : nullptr);
                 xn_deferred = defer2;
@@ -1282,10 +1423,12 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
     if (xn_deferred) {       // the last FFN-down projection already produced the final norm's operand for every row
         GemmArgs al = mk(m->xn, H, m->lm_head, m->logits, m->Vpad, nullptr, 1.f, rows, m->V, H);
         set_deferred_in(m, al);
+        m->site = KS_LM_HEAD;
         gemm(m, EPI_STORE, true, al);
     } else {
         norm(m, m->x, all ? nullptr : md.last_rows, m->g[NVL_T_FINAL_NORM_W], m->g[NVL_T_FINAL_NORM_B], m->xn_last, rows);
         if (m->pending_slices != 0) throw std::runtime_error("forward: a split-K residual was left unconsumed");
+        m->site = KS_LM_HEAD;
         gemm(m, EPI_STORE, true, mk(m->xn_last, H, m->lm_head, m->logits, m->Vpad, nullptr, 1.f, rows, m->V, H));
     }
     if (seam & 4) {      // sampling reads the logits: apply LogitsScaling here (argmax_partial_kernel does it otherwise)
@@ -1296,7 +1439,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
             NVL_HIP(hipGetLastError());
         }
     } else {
-        KScope ks(m, KC_OTHER);
+        KScope ks(m, KC_OTHER, 0, KS_ARGMAX, (double)rows * m->V * 4.0);
         launch_argmax(m->stream, m->logits, m->Vpad, m->V, rows, c.logits_scaling, m->argmax_pval, m->argmax_pidx,
                       (seam & 2) ? nullptr : m->argmax_dev);
         NVL_HIP(hipGetLastError());
@@ -1369,12 +1512,14 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
     NVL_HIP(hipEventRecord(m->ev0, m->stream));
     NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, meta_bytes(m, M), hipMemcpyHostToDevice, m->stream));
 
-    double attn_flops = 0;   // 4*hd per (query, visible key) pair per head
+    double attn_flops = 0, kv_tok = 0;   // 4*hd per (query, visible key) pair per head; cached + new keys of the batch
     for (int i = 0; i < n_seqs; i++) {
         const double s = seq_lens[i], p0 = pos_offsets[i];
         attn_flops += 4.0 * m->hd * m->nH * (s * p0 + s * (s + 1) / 2);
         m->ctx_hint = std::max(m->ctx_hint, (int)(pos_offsets[i] + seq_lens[i]));
+        kv_tok += p0 + s;
     }
+    m->kv_tok = kv_tok;
     const bool all = (flags & NVL_FWD_ALL_LOGITS) != 0;
     const int rows = enqueue_forward(m, md, n_seqs, M, max_len, attn_flops, flags);
     NVL_HIP(hipEventRecord(m->ev1, m->stream));
@@ -1451,12 +1596,14 @@ extern "C" int nvl_forward_paged(nvl_model* m, int n_seqs, const int32_t* tokens
     const Meta md = bind_meta(m, m->meta_dev, M);
     NVL_HIP(hipEventRecord(m->ev0, m->stream));
     NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, meta_bytes(m, M), hipMemcpyHostToDevice, m->stream));
-    double attn_flops = 0;
+    double attn_flops = 0, kv_tok = 0;
     for (int i = 0; i < n_seqs; i++) {
         const double s = seq_lens[i], p0 = pos_offsets[i];
         attn_flops += 4.0 * m->hd * m->nH * (s * p0 + s * (s + 1) / 2);
         m->ctx_hint = std::max(m->ctx_hint, (int)(pos_offsets[i] + seq_lens[i]));
+        kv_tok += p0 + s;
     }
+    m->kv_tok = kv_tok;
     const bool all = (flags & NVL_FWD_ALL_LOGITS) != 0;
     const int rows = enqueue_forward(m, md, n_seqs, M, max_len, attn_flops, flags);
     NVL_HIP(hipEventRecord(m->ev1, m->stream));
@@ -1556,11 +1703,13 @@ void decode_loop(nvl_model* m, const Meta& hm, int n_seqs, int n_steps, int32_t*
     const bool dbg = m->keep_hidden;
     m->keep_hidden = false;                      // the per-layer taps belong to single nvl_forward calls
     for (int s = 0; s < n_steps; s++) {
-        double attn_flops = 0;
+        double attn_flops = 0, kv_tok = 0;
         for (int i = 0; i < n_seqs; i++) {
             attn_flops += 4.0 * m->hd * m->nH * (double)(h_pos[i] + s + 1);
             m->ctx_hint = std::max(m->ctx_hint, h_pos[i] + s + 1);
+            kv_tok += h_pos[i] + s + 1;
         }
+        m->kv_tok = kv_tok;
         // bf16 path: the step's tail (argmax, token feedback) and the next step's head (embedding gather + layer 0's
         // norm) are one launch (decode_seam_kernel); fp32 parity mode keeps the separate kernels
         const bool seam_ok = (g_decode_seam || sp) && !m->f32 && m->H <= 1024 * NORM_ROW_MAXCH && m->H % 4 == 0;
@@ -1817,6 +1966,20 @@ extern "C" int nvl_get_kv(nvl_model* m, int64_t seq_id, int layer, float* k_out,
     NVL_CATCH(m)
 }
 
+extern "C" int nvl_get_mamba_state(nvl_model* m, int64_t seq_id, int layer, float* out) {
+    if (!m || !out) return NVL_ERR_INVALID;
+    auto it = m->seq_slot.find(seq_id);
+    if (it == m->seq_slot.end()) return fail(m, NVL_ERR_UNKNOWN_SEQ, "nvl_get_mamba_state: unknown sequence");
+    if (layer < 0 || layer >= m->L || !m->layers[(size_t)layer].mamba) return fail(m, NVL_ERR_INVALID, "nvl_get_mamba_state: not a Mamba2 layer");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    NVL_HIP(hipStreamSynchronize(m->stream));
+    const float* src = m->ssm_state + (int64_t)it->second * m->ssm_slot_stride + (int64_t)m->layers[(size_t)layer].mamba_idx * m->ssm_layer_stride;
+    NVL_HIP(hipMemcpy(out, src, (size_t)m->ssm_layer_stride * 4, hipMemcpyDeviceToHost));
+    return (int)m->ssm_layer_stride;
+    NVL_CATCH(m)
+}
+
 extern "C" int nvl_get_kv_paged(nvl_model* m, const int32_t* block_table, int n_blocks, int n_tokens, int layer,
                                 float* k_out, float* v_out) {
     if (!m) return NVL_ERR_INVALID;
@@ -1847,7 +2010,25 @@ extern "C" int nvl_reset_stats(nvl_model* m) {
     const double wb = m->stats.weight_bytes;
     m->stats = nvl_stats{};
     m->stats.weight_bytes = wb;
+    for (auto& ph : m->site_stats) for (auto& st : ph) st = SiteStat{};
     return NVL_OK;
+}
+static const char* const k_site_names[KS_COUNT] = {
+    "other", "qkv_proj", "attention", "o_proj", "ffn_up", "ffn_down", "lm_head", "norm", "moe_router", "moe_plan", "moe_up",
+    "moe_down", "moe_combine", "embed", "argmax", "rope_kv", "mamba_in_proj", "mamba_conv", "mamba_scan", "mamba_gate_norm",
+    "mamba_out_proj", "tp_allreduce"};
+extern "C" const char* nvl_kernel_site_name(int site) { return site >= 0 && site < KS_COUNT ? k_site_names[site] : ""; }
+extern "C" int nvl_get_kernel_stats(nvl_model* m, nvl_kernel_stat* out, int cap) {
+    if (!m || (cap > 0 && !out)) return NVL_ERR_INVALID;
+    int n = 0;
+    for (int ph = 0; ph < 2; ph++)
+        for (int st = 0; st < KS_COUNT; st++) {
+            const SiteStat& ss = m->site_stats[ph][st];
+            if (!ss.launches) continue;
+            if (n < cap) out[n] = nvl_kernel_stat{st, ph, ss.launches, ss.ms, ss.flops, ss.bytes};
+            n++;
+        }
+    return n;
 }
 
 // =================================================================================================

@@ -26,6 +26,11 @@ def _cfg_struct(cfg: dict) -> L.ModelConfigC:
     c.use_moe = int(bool(cfg.get("use_moe", False)))
     for k in ("embedding_multiplier", "attention_multiplier", "residual_multiplier", "logits_scaling"):
         setattr(c, k, float(cfg.get(k, 0.0)))
+    for k in ("mamba_expand", "mamba_state_size", "mamba_num_heads", "mamba_head_dim", "mamba_n_groups", "mamba_conv_kernel"):
+        setattr(c, k, int(cfg.get(k, 0)))
+    for i, t in enumerate(cfg.get("hybrid_layers") or []):          # config.go:113 HybridLayers
+        if t in ("mamba", "mamba2"):
+            c.mamba_layer_mask[i >> 6] |= 1 << (i & 63)
     return c
 
 
@@ -82,6 +87,10 @@ class HipTransformerModel:
         cfg = {}
         for name, _ in L.ModelConfigC._fields_:
             v = getattr(c, name)
+            if name == "mamba_layer_mask":
+                if v[0] | v[1]:
+                    cfg["hybrid_layers"] = ["mamba" if (v[i >> 6] >> (i & 63)) & 1 else "attention" for i in range(c.num_layers)]
+                continue
             cfg[name] = inv[name][v] if name in inv else (bool(v) if name in ("tied_embedding", "use_moe") else v)
         m = cls(cfg, None, **kw)
         L.check(m.lib.nvl_load_safetensors(m.h, path.encode()), m.h)
@@ -107,7 +116,9 @@ class HipTransformerModel:
         L.check(L.lib().nvl_tp_attach_local(arr, len(models)))
 
     # -- weights -----------------------------------------------------------------------------
-    def upload(self, slot: str, layer: int, arr, layout: int = L.LAYOUT_IN_OUT):
+    def upload(self, slot: str, layer: int, arr, layout: int | None = None):
+        if layout is None:
+            layout = L.LAYOUT_OUT_IN if slot in L.OUT_IN_SLOTS else L.LAYOUT_IN_OUT
         ptr, dtype, shape, keep = _as_pointer(arr)
         if slot in L.ONE_D:
             rows, cols = int(np.prod(shape)), 1
@@ -265,6 +276,14 @@ class HipTransformerModel:
             L.check(self.lib.nvl_get_hidden(self.h, li, _ptr(out[li]), n_tokens * self.H), self.h)
         return out
 
+    def get_mamba_state(self, seq_id: int, layer: int):
+        """Mamba2Layer.SSMState of the sequence for a Mamba2 layer, [heads, head_dim, state]."""
+        c = self.cfg
+        hd = c.get("mamba_head_dim") or c["mamba_expand"] * c["hidden"] // c["mamba_num_heads"]
+        out = np.empty((c["mamba_num_heads"], hd, c["mamba_state_size"]), np.float32)
+        L.check(self.lib.nvl_get_mamba_state(self.h, seq_id, layer, _ptr(out)), self.h)
+        return out
+
     def get_kv(self, seq_id: int, layer: int):
         T = self.seq_len(seq_id)
         at = self.cfg["attention_type"]
@@ -283,6 +302,14 @@ class HipTransformerModel:
         L.check(self.lib.nvl_get_stats(self.h, C.byref(s)), self.h)
         return {k: getattr(s, k) for k, _ in L.StatsC._fields_}
 
+    def kernel_stats(self) -> list:
+        """nvl_get_kernel_stats: [{site, phase ('prefill'|'decode'), launches, ms, flops, bytes}, ...]."""
+        n = self.lib.nvl_get_kernel_stats(self.h, None, 0)
+        arr = (L.KernelStatC * max(n, 1))()
+        n = min(n, self.lib.nvl_get_kernel_stats(self.h, arr, n))
+        return [dict(site=self.lib.nvl_kernel_site_name(arr[i].site).decode(), phase=("prefill", "decode")[arr[i].phase],
+                     launches=int(arr[i].launches), ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes) for i in range(n)]
+
     def reset_stats(self):
         L.check(self.lib.nvl_reset_stats(self.h), self.h)
 
@@ -293,6 +320,9 @@ class HipTransformerModel:
 
     def __del__(self):
         try:
+            import sys
+            if sys.is_finalizing():      # interpreter shutdown: the HIP runtime may already be gone (a leaked handle must
+                return                   # not turn into nvl_destroy -> hipFree after teardown); the OS reclaims the memory
             self.close()
         except Exception:
             pass

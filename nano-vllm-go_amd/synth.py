@@ -47,6 +47,7 @@ def make_weights(cfg: dict, seed: int = 42, scale: float = 0.02, peaked_head: fl
     t[("final_norm_w", 0)] = nw(g, H)
     if ln:
         t[("final_norm_b", 0)] = nb(g, H)
+    hybrid = cfg.get("hybrid_layers") or []
     for li in range(L):
         r = np.random.default_rng(seed + 1 + li)
         t[("attn_norm_w", li)] = nw(r, H)
@@ -56,6 +57,23 @@ def make_weights(cfg: dict, seed: int = 42, scale: float = 0.02, peaked_head: fl
             t[("ffn_norm_w", li)] = nw(r, H)
             if ln:
                 t[("ffn_norm_b", li)] = nb(r, H)
+        if li < len(hybrid) and hybrid[li] in ("mamba", "mamba2"):
+            # Mamba2Layer tensors as loadMamba2 leaves them (generic_loader.go:461-512): PyTorch layouts, NOT transposed;
+            # the block keeps its shared MLP (loadFFN) and both norms
+            EH, nh, ss, ng, K = cfg["mamba_expand"] * H, cfg["mamba_num_heads"], cfg["mamba_state_size"], cfg["mamba_n_groups"], cfg["mamba_conv_kernel"]
+            conv_dim = EH + 2 * ng * ss
+            t[("mamba_in_proj", li)] = w(r, EH + conv_dim + nh, H)
+            t[("mamba_conv_w", li)] = w(r, conv_dim, K, s=0.3)
+            t[("mamba_conv_b", li)] = nb(r, conv_dim)
+            t[("mamba_a_log", li)] = round_bf16(np.log(r.uniform(1.0, 8.0, nh)).astype(np.float32))
+            t[("mamba_d", li)] = nw(r, nh)
+            t[("mamba_dt_bias", li)] = round_bf16(r.uniform(-3.0, 0.5, nh).astype(np.float32))
+            t[("mamba_norm", li)] = nw(r, EH)
+            t[("mamba_out_proj", li)] = w(r, H, EH)
+            n1 = 2 * F if cfg["activation_type"] == "swiglu" else F
+            t[("w1", li)] = w(r, H, n1)
+            t[("w2", li)] = w(r, F, H)
+            continue
         t[("wq", li)] = w(r, H, nH * hd)
         if at == "mqa":
             t[("wkv", li)] = w(r, H, 2 * hd)
@@ -102,6 +120,15 @@ def tiny_config(family: str, **over) -> dict:
                     num_experts=8, num_experts_per_tok=2, tied_embedding=True, vocab_size=1027,
                     embedding_multiplier=12.0, attention_multiplier=0.015625, residual_multiplier=0.22,
                     logits_scaling=6.0, norm_eps=1e-6)
+    elif family == "granite_hybrid":
+        # Granite-4 hybrid (config.go:241-330): GQA attention WITHOUT positional encoding + Mamba2 blocks, shared SwiGLU MLP,
+        # muP multipliers; tiny sizes that keep the real ratios (heads x head_dim = expand x hidden)
+        base.update(attention_type="gqa", norm_type="rmsnorm", position_type="nope", activation_type="swiglu",
+                    block_style="sequential", num_heads=4, num_kv_heads=2, hidden=128, ffn_dim=256, num_layers=4,
+                    tied_embedding=True, vocab_size=1019, embedding_multiplier=12.0, attention_multiplier=0.015625,
+                    residual_multiplier=0.22, logits_scaling=6.0, norm_eps=1e-5,
+                    mamba_expand=2, mamba_state_size=32, mamba_num_heads=8, mamba_head_dim=32, mamba_n_groups=2,
+                    mamba_conv_kernel=4, hybrid_layers=["mamba", "attention", "mamba", "mamba"])
     else:
         raise ValueError(family)
     base.update(over)

@@ -554,6 +554,7 @@ struct po_model {
     float* rope_cos; /* one table serves all layers: the reference builds L identical copies
                         (generic_model.go:109-111) */
     float* rope_sin;
+    float** ssm_state; /* per layer: Mamba2Layer.SSMState [heads, head_dim, state] (batch 1), NULL = nil (mamba2.go:258) */
 };
 
 struct po_kvcache {
@@ -566,6 +567,7 @@ po_model* po_model_new(const po_config* cfg) {
     po_model* m = (po_model*)calloc(1, sizeof(po_model));
     m->cfg = *cfg;
     m->layer = (po_slot*)calloc((size_t)cfg->num_layers * PO_T_COUNT, sizeof(po_slot));
+    m->ssm_state = (float**)calloc((size_t)cfg->num_layers, sizeof(float*));
     int uses_rope = 0;
     double base = cfg->rope_base;
     if (cfg->attention_type == PO_ATTN_MQA) { uses_rope = 1; base = 10000.0; } /* mqa.go:35 ignores rope_theta */
@@ -583,6 +585,8 @@ void po_model_free(po_model* m) {
     if (!m) return;
     for (int s = 0; s < PO_T_COUNT; s++) free(m->global[s].owned);
     for (int64_t i = 0; i < (int64_t)m->cfg.num_layers * PO_T_COUNT; i++) free(m->layer[i].owned);
+    po_mamba2_reset(m);
+    free(m->ssm_state);
     free(m->layer); free(m->rope_cos); free(m->rope_sin); free(m);
 }
 
@@ -739,12 +743,153 @@ static void residual_add(float* x /* new */, const float* residual, float mult, 
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* Mamba2: purego/tensor/mamba2.go                                           */
+/* ------------------------------------------------------------------------ */
+
+/* ResetState, mamba2.go:353-357 (called by ForwardWithCache for a brand-new sequence, generic_model.go:285-292) */
+void po_mamba2_reset(po_model* m) {
+    for (int li = 0; li < m->cfg.num_layers; li++) { free(m->ssm_state[li]); m->ssm_state[li] = NULL; }
+}
+int po_mamba2_get_state(const po_model* m, int layer, float* out) {
+    const po_config* c = &m->cfg;
+    int hd = c->mamba_head_dim ? c->mamba_head_dim : (c->mamba_num_heads ? c->mamba_expand * c->hidden / c->mamba_num_heads : 0);
+    int n = c->mamba_num_heads * hd * c->mamba_state_size;
+    if (layer < 0 || layer >= c->num_layers || !m->ssm_state[layer]) return 0;
+    memcpy(out, m->ssm_state[layer], (size_t)n * sizeof(float));
+    return n;
+}
+
+/* Softplus, mamba2.go:370-376 */
+static float softplus_f(float x) { return (float)log(1.0 + exp((double)x)); }
+
+/* Mamba2Layer.Forward, mamba2.go:74-181 (batch = 1).  x [S, H] -> out [S, H] (caller frees). */
+static float* mamba2_forward(po_model* m, int li, const float* x, int S) {
+    const po_config* c = &m->cfg;
+    const int H = c->hidden, EH = c->mamba_expand * c->hidden, nh = c->mamba_num_heads, ss = c->mamba_state_size;
+    const int hd = c->mamba_head_dim ? c->mamba_head_dim : EH / nh;           /* mamba2.go:58-61 */
+    const int ng = c->mamba_n_groups, K = c->mamba_conv_kernel;
+    const int gate_size = EH, conv_dim = EH + 2 * ng * ss, dt_size = nh;      /* :92-95 (ConvWeight.Shape[0]) */
+    const int P = gate_size + conv_dim + dt_size;
+    const float* in_proj = L_(PO_T_MAMBA_IN_PROJ);
+
+    /* 1. projected = MatMul(xFlat, Transpose(InProj)) :89-90 — Transpose materialises [H, P], then the i-p-j MatMul */
+    float* in_t = fzeros((int64_t)H * P);
+    po_transpose(in_proj, in_t, P, H);
+    float* proj = fzeros((int64_t)S * P);
+    po_matmul(x, in_t, proj, S, H, P);
+    free(in_t);
+    /* split [gate | xBC | dt] :98-100 */
+    /* 2. causal conv on xBC :107, mamba2.go:183-254: left zero padding of K-1, "forward" kernel, first S positions.
+     *    NOTE (reference behaviour): no convolution state is carried across calls (ConvCache is never used), so a
+     *    one-token decode call convolves the token with zeros. */
+    const int pad = K - 1, PS = S + pad;
+    const float* cw = L_(PO_T_MAMBA_CONV_W);
+    const float* cb = L_(PO_T_MAMBA_CONV_B);
+    float* padded = fzeros((int64_t)PS * conv_dim);
+    for (int t = 0; t < S; t++)
+        memcpy(padded + (int64_t)(t + pad) * conv_dim, proj + (int64_t)t * P + gate_size, (size_t)conv_dim * sizeof(float));
+    float* xbc = fzeros((int64_t)S * conv_dim);
+    for (int t = 0; t < S; t++)               /* only the first S of the PS computed positions are kept (:241-251) */
+        for (int ch = 0; ch < conv_dim; ch++) {
+            float sum = 0.0f;
+            for (int k = 0; k < K; k++) {
+                int pos = t + k;
+                if (pos >= 0 && pos < PS) {
+                    float prod = padded[(int64_t)pos * conv_dim + ch] * cw[(int64_t)ch * K + k];
+                    sum = sum + prod;
+                }
+            }
+            if (cb) sum = sum + cb[ch];
+            xbc[(int64_t)t * conv_dim + ch] = sum;
+        }
+    free(padded);
+    /* 3. SiLU :110 */
+    po_silu(xbc, xbc, (int64_t)S * conv_dim);
+    /* 4. split x | B | C :115-117; 5. delta = Softplus(dt + bias) :124-131 */
+    float* delta = fzeros((int64_t)S * nh);
+    const float* dtb = L_(PO_T_MAMBA_DT_BIAS);
+    for (int t = 0; t < S; t++)
+        for (int h = 0; h < nh; h++) {
+            float v = proj[(int64_t)t * P + gate_size + conv_dim + h];
+            if (dtb) v = v + dtb[h];
+            delta[(int64_t)t * nh + h] = softplus_f(v);
+        }
+    /* 6. selectiveScan :256-351 */
+    if (!m->ssm_state[li]) m->ssm_state[li] = fzeros((int64_t)nh * hd * ss);
+    float* state = m->ssm_state[li];
+    const float* alog = L_(PO_T_MAMBA_A_LOG);
+    const float* Dp = L_(PO_T_MAMBA_D);
+    float* y = fzeros((int64_t)S * EH);
+    for (int t = 0; t < S; t++)
+        for (int h = 0; h < nh; h++) {
+            const float dt = delta[(int64_t)t * nh + h];
+            float abar = 1.0f;
+            if (alog) {
+                float A = -(float)exp((double)alog[h]);           /* :286 */
+                abar = (float)exp((double)(A * dt));              /* :287 */
+            }
+            int g = h * ng / nh;                                  /* :301-304 */
+            if (g >= ng) g = ng - 1;
+            const float* u = xbc + (int64_t)t * conv_dim + (int64_t)h * hd;
+            const float* Bt = xbc + (int64_t)t * conv_dim + EH + (int64_t)g * ss;
+            const float* Ct = xbc + (int64_t)t * conv_dim + EH + (int64_t)ng * ss + (int64_t)g * ss;
+            for (int d = 0; d < hd; d++)
+                for (int s2 = 0; s2 < ss; s2++) {
+                    float* st = state + ((int64_t)h * hd + d) * ss + s2;
+                    float a = abar * *st;                         /* :325: ABar*oldState + dt*Bt[s]*u[d] (left to right) */
+                    float b = dt * Bt[s2];
+                    b = b * u[d];
+                    *st = a + b;
+                }
+            for (int d = 0; d < hd; d++) {
+                float sum = 0.0f;
+                for (int s2 = 0; s2 < ss; s2++) {
+                    float prod = Ct[s2] * state[((int64_t)h * hd + d) * ss + s2];
+                    sum = sum + prod;
+                }
+                if (Dp) { float prod = Dp[h] * u[d]; sum = sum + prod; }      /* :339-341 */
+                y[(int64_t)t * EH + (int64_t)h * hd + d] = sum;
+            }
+        }
+    /* 7. gated RMSNorm :135-170: y *= SiLU(gate); rms over EH with eps 1e-5; *= Norm */
+    {
+        float* gact = fzeros((int64_t)S * gate_size);
+        for (int t = 0; t < S; t++) memcpy(gact + (int64_t)t * gate_size, proj + (int64_t)t * P, (size_t)gate_size * sizeof(float));
+        po_silu(gact, gact, (int64_t)S * gate_size);
+        for (int64_t i = 0; i < (int64_t)S * EH; i++) y[i] = y[i] * gact[i];
+        free(gact);
+        const float eps = 1e-5f;
+        for (int t = 0; t < S; t++) {
+            float var = 0.0f;
+            float* yr = y + (int64_t)t * EH;
+            for (int d = 0; d < EH; d++) { float prod = yr[d] * yr[d]; var = var + prod; }
+            var = var / (float)EH;
+            float rms = 1.0f / (float)sqrt((double)(var + eps));
+            for (int d = 0; d < EH; d++) yr[d] = yr[d] * rms;
+        }
+        const float* nw = L_(PO_T_MAMBA_NORM);
+        if (nw) for (int64_t i = 0; i < (int64_t)S * EH; i++) y[i] = y[i] * nw[i % EH];
+    }
+    /* 9. output = MatMul(yFlat, Transpose(OutProj)) :173-176 */
+    const float* out_proj = L_(PO_T_MAMBA_OUT_PROJ);
+    float* out_t = fzeros((int64_t)EH * H);
+    po_transpose(out_proj, out_t, H, EH);
+    float* out = fzeros((int64_t)S * H);
+    po_matmul(y, out_t, out, S, EH, H);
+    free(out_t); free(y); free(delta); free(xbc); free(proj);
+    return out;
+}
+
 int po_forward_with_cache(po_model* m, const int32_t* tokens, int n_tokens,
                           po_kvcache* kv, int pos_offset, float* logits_out, float* hidden_out) {
     const po_config* c = &m->cfg;
     int H = c->hidden, S = n_tokens, V = c->vocab_size;
     int err = 0;
     int64_t n = (int64_t)S * H;
+
+    /* Mamba2 state is reset only for a brand-new sequence, generic_model.go:285-292 (posOffset == 0 && seqLen > 1) */
+    if (pos_offset == 0 && S > 1) po_mamba2_reset(m);
 
     /* embedWithOffset, generic_model.go:567-592 */
     float* x = fzeros(n);
@@ -766,7 +911,23 @@ int po_forward_with_cache(po_model* m, const int32_t* tokens, int n_tokens,
 
     float* normed = fzeros(n);
     for (int li = 0; li < c->num_layers; li++) {
-        if (c->attention_type == PO_ATTN_MQA && c->block_style == PO_BLOCK_PARALLEL) {
+        if (li < 128 && c->layer_is_mamba[li]) {
+            /* block.Forward -> forwardMamba2, generic_model.go:456-459, 160-202: norm, Mamba2, residual; norm, FFN, residual */
+            po_layernorm(x, L_(PO_T_ATTN_NORM_W), L_(PO_T_ATTN_NORM_B), c->norm_eps, normed, S, H);
+            float* mo = mamba2_forward(m, li, normed, S);
+            residual_add(mo, x, c->residual_multiplier, n);
+            memcpy(x, mo, (size_t)n * sizeof(float));
+            free(mo);
+            if (L_(PO_T_W1)) {
+                po_layernorm(x, L_(PO_T_FFN_NORM_W), L_(PO_T_FFN_NORM_B), c->norm_eps, normed, S, H);
+                float* f = fzeros(n);
+                po_ffn(normed, L_(PO_T_W1), L_(PO_T_B1), L_(PO_T_W2), L_(PO_T_B2), S, H, c->ffn_dim,
+                       c->activation_type == PO_ACT_SWIGLU, f);
+                residual_add(f, x, c->residual_multiplier, n);
+                memcpy(x, f, (size_t)n * sizeof(float));
+                free(f);
+            }
+        } else if (c->attention_type == PO_ATTN_MQA && c->block_style == PO_BLOCK_PARALLEL) {
             /* generic_model.go:395-418 */
             po_layernorm(x, L_(PO_T_ATTN_NORM_W), L_(PO_T_ATTN_NORM_B), c->norm_eps, normed, S, H);
             float* attn = attention_layer(m, li, normed, S, kv, pos_offset, &err);

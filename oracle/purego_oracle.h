@@ -46,6 +46,10 @@ typedef struct po_config {
     int32_t tied_embedding;
     int32_t use_moe, num_experts, num_experts_per_tok;
     float   embedding_multiplier, attention_multiplier, residual_multiplier, logits_scaling;
+    /* Mamba2 / hybrid layers (config.go:100-115): layer li is a Mamba2 block when layer_is_mamba[li] != 0
+     * (HybridLayers[li] == "mamba" / "mamba2", generic_model.go:50-53, 74-76) */
+    int32_t mamba_expand, mamba_state_size, mamba_num_heads, mamba_head_dim, mamba_n_groups, mamba_conv_kernel;
+    uint8_t layer_is_mamba[128];
 } po_config;
 
 /* Tensor slots, in the layout the reference holds AFTER loading
@@ -74,6 +78,15 @@ enum {
     PO_T_ROUTER,        /* [H, E]        moe.go:12                         */
     PO_T_MOE_IN,        /* [E, 2I, H]    moe.go:176 (NOT transposed)       */
     PO_T_MOE_OUT,       /* [E, H, I]                                       */
+    /* Mamba2Layer (mamba2.go:9-27), as loadMamba2 leaves them (generic_loader.go:461-512: NO transpose) */
+    PO_T_MAMBA_IN_PROJ, /* [gate + conv_dim + heads, H]   PyTorch [out, in]; used as MatMul(x, Transpose(InProj)) mamba2.go:90 */
+    PO_T_MAMBA_CONV_W,  /* [conv_dim, 1, K]                                 */
+    PO_T_MAMBA_CONV_B,  /* [conv_dim]                                       */
+    PO_T_MAMBA_A_LOG,   /* [heads]                                          */
+    PO_T_MAMBA_D,       /* [heads]                                          */
+    PO_T_MAMBA_DT_BIAS, /* [heads]                                          */
+    PO_T_MAMBA_NORM,    /* [expand * H]                                     */
+    PO_T_MAMBA_OUT_PROJ,/* [H, expand * H]           PyTorch [out, in]; MatMul(y, Transpose(OutProj)) mamba2.go:175 */
     PO_T_COUNT
 };
 
@@ -100,6 +113,11 @@ int         po_kvcache_get(const po_kvcache* kv, int layer, int which, float* ou
 int po_forward_with_cache(po_model* m, const int32_t* tokens, int n_tokens,
                           po_kvcache* kv, int pos_offset,
                           float* logits_out, float* hidden_out);
+
+/* Mamba2Layer.Forward (mamba2.go:74-181) on x [S, H] -> out [S, H], with the layer's persistent SSM state
+ * (mamba2.go:29-30, 258-260); the model resets it like ForwardWithCache does (generic_model.go:285-292). */
+void po_mamba2_reset(po_model* m);
+int  po_mamba2_get_state(const po_model* m, int layer, float* out);   /* [heads, head_dim, state]; returns floats */
 
 /* test-time knobs, not part of the restated algorithm (see purego_oracle.c): row-parallel MatMul (bit-identical per
  * row; default 1 thread like the reference) and "LM head on the last row only" (logits_out becomes [1, V]) */

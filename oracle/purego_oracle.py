@@ -22,6 +22,7 @@ SLOTS = [
     "attn_norm_w", "attn_norm_b", "ffn_norm_w", "ffn_norm_b",
     "wq", "wk", "wv", "wkv", "wo", "bq", "bk", "bv", "bo",
     "w1", "b1", "w2", "b2", "router", "moe_in", "moe_out",
+    "mamba_in_proj", "mamba_conv_w", "mamba_conv_b", "mamba_a_log", "mamba_d", "mamba_dt_bias", "mamba_norm", "mamba_out_proj",
 ]
 SLOT_ID = {n: i for i, n in enumerate(SLOTS)}
 GLOBAL_SLOTS = set(SLOTS[:5])
@@ -44,6 +45,9 @@ class PoConfig(C.Structure):
         ("use_moe", C.c_int32), ("num_experts", C.c_int32), ("num_experts_per_tok", C.c_int32),
         ("embedding_multiplier", C.c_float), ("attention_multiplier", C.c_float),
         ("residual_multiplier", C.c_float), ("logits_scaling", C.c_float),
+        ("mamba_expand", C.c_int32), ("mamba_state_size", C.c_int32), ("mamba_num_heads", C.c_int32),
+        ("mamba_head_dim", C.c_int32), ("mamba_n_groups", C.c_int32), ("mamba_conv_kernel", C.c_int32),
+        ("layer_is_mamba", C.c_uint8 * 128),
     ]
 
 
@@ -76,6 +80,8 @@ def lib():
         L.po_forward_with_cache.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_void_p]
         L.po_argmax.argtypes = [C.c_void_p, C.c_int]
+        L.po_mamba2_reset.argtypes = [C.c_void_p]
+        L.po_mamba2_get_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.po_set_threads.argtypes = [C.c_int]
         L.po_set_lm_head_last_only.argtypes = [C.c_int]
         L.po_sample_with_history.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int,
@@ -128,6 +134,10 @@ def make_config(cfg: dict) -> PoConfig:
     c.use_moe = int(bool(cfg.get("use_moe", False)))
     for k in ("embedding_multiplier", "attention_multiplier", "residual_multiplier", "logits_scaling"):
         setattr(c, k, float(cfg.get(k, 0.0)))
+    for k in ("mamba_expand", "mamba_state_size", "mamba_num_heads", "mamba_head_dim", "mamba_n_groups", "mamba_conv_kernel"):
+        setattr(c, k, int(cfg.get(k, 0)))
+    for i, t in enumerate(cfg.get("hybrid_layers", []) or []):     # config.go:113 HybridLayers: "attention" | "mamba" | "mamba2"
+        c.layer_is_mamba[i] = 1 if t in ("mamba", "mamba2") else 0
     return c
 
 
@@ -192,6 +202,16 @@ class OracleModel:
         if rc != 0:
             raise RuntimeError("oracle: the reference panics on this input (position or token out of range)")
         return (logits, hidden) if want_hidden else logits
+
+    def mamba_state(self, layer: int):
+        """Mamba2Layer.SSMState of a layer, [heads, head_dim, state] (None while nil)."""
+        c = self.cfg
+        hd = c.get("mamba_head_dim") or c["mamba_expand"] * c["hidden"] // c["mamba_num_heads"]
+        out = np.empty((c["mamba_num_heads"], hd, c["mamba_state_size"]), np.float32)
+        return out if lib().po_mamba2_get_state(self.h, int(layer), _p(out)) else None
+
+    def reset_mamba(self):
+        lib().po_mamba2_reset(self.h)
 
     def greedy(self, prompt, max_tokens: int, return_margins: bool = False):
         """cmd/ask/main.go:287-360 generateResponse with argmax, no EOS stop (ignore_eos).

@@ -12,7 +12,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(names) >= 30 and "nvl_forward" in names and "nvl_runner_run" in names
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.nvl_abi_version() == 1
+    assert L.nvl_abi_version() == 2
 
 
 def test_header_cites_the_reference_for_every_entry_point(pkg):
@@ -26,12 +26,12 @@ def test_header_cites_the_reference_for_every_entry_point(pkg):
 def test_struct_mirrors_match_the_header(pkg):
     L = pkg._lib
     lib = pkg.lib()
-    assert C.sizeof(L.ModelConfigC) == lib.nvl_sizeof(0) == 104     # 13 x i32, pad, f64, f32, i32, 3 x i32, 4 x f32, pad
+    assert C.sizeof(L.ModelConfigC) == lib.nvl_sizeof(0) == 144     # 13 x i32, pad, f64, f32, i32, 3 x i32, 4 x f32, 6 x i32 (Mamba2), 2 x u64
     assert C.sizeof(L.RuntimeOptsC) == lib.nvl_sizeof(1) == 40
     assert C.sizeof(L.StatsC) == lib.nvl_sizeof(2) == 15 * 8
     assert C.sizeof(L.SamplingParamsC) == lib.nvl_sizeof(3) == 16
     assert [n for n, _ in L.ModelConfigC._fields_][:3] == ["vocab_size", "hidden", "num_layers"]
-    assert len(L.SLOTS) == 25 and L.SLOT_ID["moe_out"] == 24      # NVL_T_COUNT
+    assert len(L.SLOTS) == 33 and L.SLOT_ID["moe_out"] == 24 and L.SLOT_ID["mamba_out_proj"] == 32      # NVL_T_COUNT
 
 
 def test_no_cpu_fallback(pkg):

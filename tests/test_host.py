@@ -88,6 +88,11 @@ def test_native_config_loader_matches_python_mirror(pkg, tmp_path):
              tie_word_embeddings=True, rms_norm_eps=1e-6, rope_theta=10000),
         dict(architecture="llama", hidden_size=512, num_heads=8, num_kv_heads=2, num_layers=4),
         dict(some_unknown_thing=1),                                  # default: GPT-2 template (:1005)
+        dict(model_type="granitemoehybrid", vocab_size=100352, hidden_size=768, num_hidden_layers=6, num_attention_heads=12,
+             num_key_value_heads=4, intermediate_size=2048, num_local_experts=0, mamba_n_heads=48, mamba_d_head=32,
+             mamba_d_state=128, mamba_n_groups=1, mamba_d_conv=4, mamba_expand=2, embedding_multiplier=12.0,
+             layer_types=["mamba", "mamba", "attention", "mamba", "attention", "mamba"], tie_word_embeddings=True),
+        dict(model_type="granitemoehybrid", hidden_size=1536),       # the "1b" template, no layer_types: all Mamba2
     ]
     enum = dict(attention_type=["mha", "mqa", "gqa"], norm_type=["layernorm", "rmsnorm"],
                 position_type=["learned", "rope", "nope"], activation_type=["gelu", "swiglu"],
@@ -102,6 +107,9 @@ def test_native_config_loader_matches_python_mirror(pkg, tmp_path):
             if name.startswith("_"):
                 continue
             g, w = getattr(got, name), getattr(want, name)
+            if name == "mamba_layer_mask":
+                assert [int(g[0]), int(g[1])] == w, (i, name, list(g), w)
+                continue
             if name in enum:
                 assert enum[name][g] == w, (i, name)
             elif isinstance(w, bool):
