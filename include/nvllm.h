@@ -311,6 +311,8 @@ typedef struct nvl_stats {
     double   weight_bytes;                /* bytes of weights resident on the device                  */
     uint64_t evictions;                   /* KV slots reclaimed from the least-recently-forwarded sequence by
                                              nvl_runner_run / _sampled when every slot was taken            */
+    uint64_t graph_replays;               /* decode passes issued as ONE hipGraphLaunch (a pass whose launch configuration was
+                                             seen before is captured once and replayed; nvl_set_tuning key 21 = 0 turns it off) */
 } nvl_stats;
 /* Per-launch-site view of the same events (nvl_set_profile on): one entry per (phase, site) that launched — QKV / O /
  * FFN-up / FFN-down projections, attention, LM head, norms, MoE stages ... — with its launch count, summed device time

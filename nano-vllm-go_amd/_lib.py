@@ -74,7 +74,7 @@ class StatsC(C.Structure):
                 ("gemm_ms", C.c_double), ("gemm_flops", C.c_double), ("gemm_launches", C.c_uint64),
                 ("attn_ms", C.c_double), ("attn_flops", C.c_double), ("attn_launches", C.c_uint64),
                 ("other_ms", C.c_double), ("other_launches", C.c_uint64), ("weight_bytes", C.c_double),
-                ("evictions", C.c_uint64)]
+                ("evictions", C.c_uint64), ("graph_replays", C.c_uint64)]
 
 
 class KernelStatC(C.Structure):         # nvl_kernel_stat

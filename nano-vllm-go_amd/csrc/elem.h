@@ -441,7 +441,8 @@ __global__ __launch_bounds__(256) void decode_seam_kernel(const float* __restric
                                                           int chunks, const int32_t* __restrict__ sampled,
                                                           int32_t* __restrict__ hist, int64_t hist_stride,
                                                           int32_t* __restrict__ hist_len, int32_t* __restrict__ argmax_out,
-                                                          int32_t* __restrict__ ring_out, int32_t* __restrict__ tokens,
+                                                          int32_t* __restrict__ ring_out, const int32_t* __restrict__ ring_pos0,
+                                                          int ring_rows, int32_t* __restrict__ tokens,
                                                           int32_t* __restrict__ tok_pos, int32_t* __restrict__ seq_pos,
                                                           const bf16_t* __restrict__ emb, const bf16_t* __restrict__ pos_emb,
                                                           int max_seq, float mult, float* __restrict__ x,
@@ -467,7 +468,8 @@ __global__ __launch_bounds__(256) void decode_seam_kernel(const float* __restric
                 hist_len[r] = n + 1;
             }
             const int pos = tok_pos[r] + 1;
-            argmax_out[r] = t; ring_out[r] = t; tokens[r] = t;
+            // ring row = steps since the loop started (from the positions, so every step's launch has the same arguments)
+            argmax_out[r] = t; ring_out[(int64_t)(pos - 1 - ring_pos0[r]) * ring_rows + r] = t; tokens[r] = t;
             tok_pos[r] = pos; seq_pos[r] = pos;          // (one token per sequence: row r IS sequence r)
             tok_s = t; pos_s = pos;
         }

@@ -2,7 +2,9 @@
 // workspaces, the HIP stream) and the kernel launch helpers shared by nvllm.hip and ops.hip.
 #pragma once
 #include <condition_variable>
+#include <array>
 #include <map>
+#include <set>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -135,6 +137,12 @@ struct nvl_model {
     float* samp_u_steps = nullptr; int64_t samp_u_cap = 0;
     int last_rows = 0;           // logits rows the last forward left in `logits`
     int32_t* ring = nullptr; int64_t ring_ints = 0;   // nvl_decode_greedy: [steps][seqs] tokens on the device
+    int32_t* ring_pos0 = nullptr;                     // position of every sequence when the fused loop started (ring row index)
+    // hipGraph replay of decode passes (one graph per launch configuration; first sight eager, second captured, then replayed)
+    std::map<std::array<int, 5>, hipGraphExec_t> graphs;
+    std::set<std::array<int, 5>> graph_seen;
+    bool graphs_ok = true;
+    int32_t* am_host = nullptr;                       // pinned: argmax ids of a replayed decode pass
     // debug
     bool keep_hidden = false; float* hidden = nullptr; int64_t hidden_tokens = 0; int hidden_last_M = 0;
     // stats

@@ -63,6 +63,11 @@ void* dmalloc_bytes(int64_t n) {
     return p;
 }
 void dfree(void* p) { if (p) (void)hipFree(p); }
+void clear_graphs(nvl_model* m) {      // captured decode passes (replay_or_capture)
+    for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+    m->graphs.clear();
+    m->graph_seen.clear();
+}
 void free_sample_bufs(SampleBufs& b) {
     dfree(b.work); dfree(b.cnt); dfree(b.hist); dfree(b.off); dfree(b.out); dfree(b.u); dfree(b.probs);
     b = SampleBufs{};
@@ -300,6 +305,9 @@ extern "C" void nvl_destroy(nvl_model* m) {
     dfree(m->xn_last); dfree(m->logits); dfree(m->argmax_dev); dfree(m->argmax_pval); dfree(m->argmax_pidx); dfree(m->router_logits); dfree(m->expert_ids);
     dfree(m->expert_w); dfree(m->seg_start); dfree(m->moe_counts); dfree(m->moe_cursor); dfree(m->moe_tile_map); dfree(m->moe_n_mtiles); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo); dfree(m->moe_xg);
     dfree(m->meta_dev); dfree(m->hidden); dfree(m->sk_part); dfree(m->tp_part); dfree(m->ring); dfree(m->rs_part);
+    clear_graphs(m);
+    if (m->am_host) (void)hipHostFree(m->am_host);
+    dfree(m->ring_pos0);
     dfree(m->ssm_state); dfree(m->mproj); dfree(m->mxbc); dfree(m->mdelta); dfree(m->my); dfree(m->myn);
     free_sample_bufs(m->samp);
     dfree(m->samp_hist); dfree(m->samp_hist_len); dfree(m->samp_u_steps);
@@ -769,6 +777,8 @@ extern "C" int nvl_finalize(nvl_model* m) {
     m->meta_ints = 3 * Mmax + 5 * S + m->table_cap + 16;
     NVL_HIP(hipHostMalloc((void**)&m->meta_host, (size_t)m->meta_ints * 4, hipHostMallocDefault));
     m->meta_dev = dmalloc<int32_t>(m->meta_ints);
+    NVL_HIP(hipHostMalloc((void**)&m->am_host, (size_t)std::max<int64_t>(S, Mmax) * 4, hipHostMallocDefault));
+    m->ring_pos0 = dmalloc<int32_t>(S);
     NVL_HIP(hipStreamSynchronize(m->stream));   // every memset/copy above ran on the model's own (non-blocking) stream
     m->finalized = true;
     return NVL_OK;
@@ -943,8 +953,19 @@ void norm(nvl_model* m, float* x, const int32_t* rows_idx, const DevTensor& w, c
     NVL_HIP(hipGetLastError());
 }
 
+static int g_use_graphs = 1;   // nvl_set_tuning key 21: hipGraph replay of decode passes (0 = every launch eager)
+static int g_tune_epoch = 0;   // bumped by every nvl_set_tuning: captured graphs bake the tuning in (part of their key)
 static int g_attn_nw = 0;      // nvl_set_tuning key 15: waves per decode-attention workgroup (0 = from the context length, 2, 4, 8)
 static int g_attn_tq2 = 1;     // nvl_set_tuning key 10: unused since round 2 (the prefill kernel always keeps two sub-tiles per wave)
+// waves per decode-attention workgroup for the batch being enqueued (also part of a captured graph's key)
+int decode_attn_waves(const nvl_model* m, int n_seqs) {
+    const int n_kt = m->ctx_hint > 0 ? (m->ctx_hint - 1) / 64 + 1 : 1 << 20;
+    const int per_wave = m->hd == 64 ? 2 : 1;
+    const int wgs = m->nKV * n_seqs;
+    const int cap = wgs >= 512 ? 2 : (wgs >= 320 ? 4 : 8);
+    const int nw = n_kt <= 2 * per_wave ? 2 : (n_kt <= 4 * per_wave ? 4 : 8);
+    return g_attn_nw ? g_attn_nw : std::min(nw, cap);
+}
 void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, double flops, bool fused_qkv = false) {
     AttnArgs a{};
     a.q = m->q; a.q_stride = m->nH * m->hd;
@@ -967,12 +988,7 @@ void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, do
         // need fewer than 8 waves (idle waves still cost LDS and a slot in the final merge), and once the grid alone
         // fills the chip (>= 2 workgroups per CU) fewer, longer-running waves stream better than many short ones
         // (profiles/r01g_decode_attention_waves.txt).  ctx_hint = the batch's longest context when the caller knows it.
-        const int n_kt = m->ctx_hint > 0 ? (m->ctx_hint - 1) / 64 + 1 : 1 << 20;
-        const int per_wave = m->hd == 64 ? 2 : 1;
-        const int wgs = m->nKV * n_seqs;
-        const int cap = wgs >= 512 ? 2 : (wgs >= 320 ? 4 : 8);
-        int nw = n_kt <= 2 * per_wave ? 2 : (n_kt <= 4 * per_wave ? 4 : 8);
-        nw = g_attn_nw ? g_attn_nw : std::min(nw, cap);
+        const int nw = decode_attn_waves(m, n_seqs);
         if (fused_qkv) {   // RoPE + KV append + attention in one launch, straight from the QKV projection's fp32 output
             a.qkv = m->qkv; a.qkv_stride = m->n_qkv; a.cos_t = m->rope_cos; a.sin_t = m->rope_sin;
         }
@@ -1249,6 +1265,40 @@ void moe(nvl_model* m, const LayerW& l, int M) {
 }  // namespace
 
 namespace {
+// ---- hipGraph replay of decode passes ----------------------------------------------------------------------------------
+// A decode pass is ~85 dependent launches of a few microseconds each.  A pass whose launch configuration (the key) has been
+// seen before is captured once from the model's stream and replayed with hipGraphLaunch: the arguments of every launch are
+// device buffers whose CONTENTS change (token ids, positions, block tables, KV slabs), never their addresses.  First sight
+// of a key runs eagerly (it also sets the per-function attributes, which must not happen during capture).
+template <typename F>
+bool replay_or_capture(nvl_model* m, const std::array<int, 5>& key, F&& enqueue) {
+    if (!g_use_graphs || !m->graphs_ok || m->profile || m->keep_hidden || m->tp > 1 || m->tp_force) return false;
+    auto it = m->graphs.find(key);
+    if (it != m->graphs.end()) { NVL_HIP(hipGraphLaunch(it->second, m->stream)); m->stats.graph_replays++; return true; }
+    if (!m->graph_seen.count(key)) { m->graph_seen.insert(key); return false; }
+    if (m->graphs.size() >= 64) clear_graphs(m);         // (keys come and go with the context length: keep the table small)
+    if (hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); m->graphs_ok = false; return false; }
+    hipGraph_t g = nullptr;
+    try {
+        enqueue();
+    } catch (...) {
+        (void)hipStreamEndCapture(m->stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        m->graphs_ok = false;
+        throw;
+    }
+    if (hipStreamEndCapture(m->stream, &g) != hipSuccess || !g) { (void)hipGetLastError(); m->graphs_ok = false; enqueue(); return true; }
+    hipGraphExec_t ge = nullptr;
+    const hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess || !ge) { (void)hipGetLastError(); m->graphs_ok = false; enqueue(); return true; }
+    m->graphs[key] = ge;
+    NVL_HIP(hipGraphLaunch(ge, m->stream));
+    m->stats.graph_replays++;
+    return true;
+}
+
 // Enqueue ONE forward pass (embedding ... argmax) on the model's stream for the batch described by the device
 // metadata `md` — no host synchronisation.  Returns the number of logits rows produced.
 // seam: 0 = whole pass; bit 0 = x and layer 0's normed operand are already in place (skip embed + first norm);
@@ -1414,6 +1464,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
     const bool all = (flags & NVL_FWD_ALL_LOGITS) != 0;
     const int rows = all ? M : n_seqs;
     if (rows > m->logit_rows) {
+        clear_graphs(m);               // (captured passes hold the old addresses)
         dfree(m->logits); dfree(m->xn_last);
         m->logits = dmalloc<float>((int64_t)rows * m->Vpad);
         m->xn_last = dmalloc_bytes(round_up(rows, 64) * H * (int64_t)m->wsize);
@@ -1510,7 +1561,6 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
     }
     const Meta md = bind_meta(m, m->meta_dev, M);
     NVL_HIP(hipEventRecord(m->ev0, m->stream));
-    NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, meta_bytes(m, M), hipMemcpyHostToDevice, m->stream));
 
     double attn_flops = 0, kv_tok = 0;   // 4*hd per (query, visible key) pair per head; cached + new keys of the batch
     for (int i = 0; i < n_seqs; i++) {
@@ -1521,17 +1571,37 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
     }
     m->kv_tok = kv_tok;
     const bool all = (flags & NVL_FWD_ALL_LOGITS) != 0;
-    const int rows = enqueue_forward(m, md, n_seqs, M, max_len, attn_flops, flags);
+    int rows = all ? M : n_seqs;
+    std::vector<int32_t> am;
+    const int32_t* am_p = nullptr;
+    bool replayed = false;
+    if (!prefill && rows <= m->logit_rows) {
+        // a decode pass (what TensorModelRunner.Run issues every step): metadata upload + all launches + the argmax
+        // download as ONE graph launch once this configuration has been seen
+        const std::array<int, 5> key{0, n_seqs, decode_attn_waves(m, n_seqs), (int)flags, g_tune_epoch};
+        replayed = replay_or_capture(m, key, [&] {
+            NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, meta_bytes(m, M), hipMemcpyHostToDevice, m->stream));
+            enqueue_forward(m, md, n_seqs, M, max_len, attn_flops, flags);
+            NVL_HIP(hipMemcpyAsync(m->am_host, m->argmax_dev, (size_t)rows * 4, hipMemcpyDeviceToHost, m->stream));
+        });
+        if (replayed) { am_p = m->am_host; m->ctx_hint = 0; }
+    }
+    if (!replayed) {
+        NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, meta_bytes(m, M), hipMemcpyHostToDevice, m->stream));
+        rows = enqueue_forward(m, md, n_seqs, M, max_len, attn_flops, flags);
+        am.resize((size_t)rows);
+        NVL_HIP(hipMemcpyAsync(am.data(), m->argmax_dev, (size_t)rows * 4, hipMemcpyDeviceToHost, m->stream));
+        am_p = am.data();
+    }
     NVL_HIP(hipEventRecord(m->ev1, m->stream));
-    std::vector<int32_t> am((size_t)rows);
-    NVL_HIP(hipMemcpyAsync(am.data(), m->argmax_dev, (size_t)rows * 4, hipMemcpyDeviceToHost, m->stream));
     if (logits_out)
         NVL_HIP(hipMemcpy2DAsync(logits_out, (size_t)m->V * 4, m->logits, (size_t)m->Vpad * 4, (size_t)m->V * 4,
                                  (size_t)rows, hipMemcpyDeviceToHost, m->stream));
     NVL_HIP(hipStreamSynchronize(m->stream));
+    m->last_rows = rows;
     if (argmax_out) {
-        if (all) for (int i = 0; i < n_seqs; i++) argmax_out[i] = am[(size_t)h_last[i]];
-        else for (int i = 0; i < n_seqs; i++) argmax_out[i] = am[(size_t)i];
+        if (all) for (int i = 0; i < n_seqs; i++) argmax_out[i] = am_p[(size_t)h_last[i]];
+        else for (int i = 0; i < n_seqs; i++) argmax_out[i] = am_p[(size_t)i];
     }
     for (int i = 0; i < n_seqs; i++) { m->slot_len[(size_t)h_slot[(size_t)i]] += seq_lens[i]; m->slot_tick[(size_t)h_slot[(size_t)i]] = ++m->tick; }
     float ms = 0.f;
@@ -1700,6 +1770,7 @@ void decode_loop(nvl_model* m, const Meta& hm, int n_seqs, int n_steps, int32_t*
     }
     NVL_HIP(hipEventRecord(m->ev0, m->stream));
     NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, meta_bytes(m, M), hipMemcpyHostToDevice, m->stream));
+    NVL_HIP(hipMemcpyAsync(m->ring_pos0, h_pos, (size_t)n_seqs * 4, hipMemcpyHostToDevice, m->stream));   // (pinned meta_host)
     const bool dbg = m->keep_hidden;
     m->keep_hidden = false;                      // the per-layer taps belong to single nvl_forward calls
     for (int s = 0; s < n_steps; s++) {
@@ -1714,6 +1785,7 @@ void decode_loop(nvl_model* m, const Meta& hm, int n_seqs, int n_steps, int32_t*
         // norm) are one launch (decode_seam_kernel); fp32 parity mode keeps the separate kernels
         const bool seam_ok = (g_decode_seam || sp) && !m->f32 && m->H <= 1024 * NORM_ROW_MAXCH && m->H % 4 == 0;
         if (sp && !seam_ok) throw std::runtime_error("sampled decode loop: bf16 models only");
+        auto one_step = [&] {
         enqueue_forward(m, md, n_seqs, M, 1, attn_flops, 0, seam_ok ? ((s > 0 ? 1 : 0) | (sp ? 4 : 2)) : 0);
         if (sp) {
             SampleArgs a{};
@@ -1730,7 +1802,8 @@ void decode_loop(nvl_model* m, const Meta& hm, int n_seqs, int n_steps, int32_t*
             const LayerW& l0 = m->layers[0];
             hipLaunchKernelGGL(decode_seam_kernel, dim3(n_seqs), dim3(256), 0, m->stream, m->argmax_pval, m->argmax_pidx,
                                cdiv(m->V, ARGMAX_CHUNK), sp ? (const int32_t*)m->samp.out : (const int32_t*)nullptr, m->samp_hist,
-                               (int64_t)m->cfg.max_seq_len, m->samp_hist_len, m->argmax_dev, m->ring + (int64_t)s * n_seqs, md.tokens, md.tok_pos,
+                               (int64_t)m->cfg.max_seq_len, m->samp_hist_len, m->argmax_dev, m->ring, (const int32_t*)m->ring_pos0, n_seqs,
+                               md.tokens, md.tok_pos,
                                md.seq_pos, (const bf16_t*)m->g[NVL_T_TOK_EMB].p, (const bf16_t*)pe, pe_rows,
                                m->cfg.embedding_multiplier, m->x, (const float*)l0.t[NVL_T_ATTN_NORM_W].p,
                                (const float*)l0.t[NVL_T_ATTN_NORM_B].p, m->cfg.norm_eps, (bf16_t*)m->xn, m->H);
@@ -1739,6 +1812,16 @@ void decode_loop(nvl_model* m, const Meta& hm, int n_seqs, int n_steps, int32_t*
                                md.tok_pos, md.seq_pos, m->ring + (int64_t)s * n_seqs, n_seqs);
         }
         NVL_HIP(hipGetLastError());
+        };
+        // steps 1.. of the greedy seam loop launch the SAME kernels with the SAME arguments (the ring row comes from the
+        // positions): one captured graph per (batch, attention wave count), replayed
+        bool replayed = false;
+        if (s > 0 && seam_ok && !sp) {
+            const std::array<int, 5> key{1, n_seqs, decode_attn_waves(m, n_seqs), 0, g_tune_epoch};
+            replayed = replay_or_capture(m, key, one_step);
+            if (replayed) m->ctx_hint = 0;
+        }
+        if (!replayed) one_step();
     }
     m->keep_hidden = dbg;
     NVL_HIP(hipEventRecord(m->ev1, m->stream));

@@ -40,6 +40,29 @@ def convert(family, sd, cfg, O):
                                         ".block_sparse_moe.experts.gate_up_proj")                        # as-is :578
                 t[("moe_out", i)] = pick(".block_sparse_moe.output_linear.weight",
                                          ".block_sparse_moe.experts.down_proj")
+    elif family == "granite_hybrid":
+        # GetGraniteMapping (generic_loader.go:145-181) + loadMamba2 (:461-512, Mamba2 tensors kept in the checkpoint's
+        # layouts) + the shared MLP every hybrid block has (shared_mlp.input_linear = gate | up fused)
+        t[("tok_emb", 0)] = _np(sd["model.embed_tokens.weight"])
+        t[("final_norm_w", 0)] = _np(sd["model.norm.weight"])
+        for i in range(L):
+            p = f"model.layers.{i}"
+            t[("attn_norm_w", i)] = _np(sd[p + ".input_layernorm.weight"])
+            t[("ffn_norm_w", i)] = _np(sd[p + ".post_attention_layernorm.weight"])
+            if cfg["hybrid_layers"][i] in ("mamba", "mamba2"):
+                t[("mamba_in_proj", i)] = _np(sd[p + ".mamba.in_proj.weight"])
+                t[("mamba_conv_w", i)] = _np(sd[p + ".mamba.conv1d.weight"]).reshape(-1, cfg["mamba_conv_kernel"])
+                t[("mamba_conv_b", i)] = _np(sd[p + ".mamba.conv1d.bias"])
+                t[("mamba_a_log", i)] = _np(sd[p + ".mamba.A_log"])
+                t[("mamba_d", i)] = _np(sd[p + ".mamba.D"])
+                t[("mamba_dt_bias", i)] = _np(sd[p + ".mamba.dt_bias"])
+                t[("mamba_norm", i)] = _np(sd[p + ".mamba.norm.weight"])
+                t[("mamba_out_proj", i)] = _np(sd[p + ".mamba.out_proj.weight"])
+            else:
+                for slot, key in (("wq", "q_proj"), ("wk", "k_proj"), ("wv", "v_proj"), ("wo", "o_proj")):
+                    t[(slot, i)] = O.transpose(_np(sd[f"{p}.self_attn.{key}.weight"]))
+            t[("w1", i)] = O.transpose(_np(sd[p + ".shared_mlp.input_linear.weight"]))     # [2F, H] -> [H, gate | up]
+            t[("w2", i)] = O.transpose(_np(sd[p + ".shared_mlp.output_linear.weight"]))
     elif family == "gpt2":
         t[("tok_emb", 0)] = _np(sd["transformer.wte.weight"])
         t[("pos_emb", 0)] = _np(sd["transformer.wpe.weight"])

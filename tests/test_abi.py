@@ -28,7 +28,7 @@ def test_struct_mirrors_match_the_header(pkg):
     lib = pkg.lib()
     assert C.sizeof(L.ModelConfigC) == lib.nvl_sizeof(0) == 144     # 13 x i32, pad, f64, f32, i32, 3 x i32, 4 x f32, 6 x i32 (Mamba2), 2 x u64
     assert C.sizeof(L.RuntimeOptsC) == lib.nvl_sizeof(1) == 40
-    assert C.sizeof(L.StatsC) == lib.nvl_sizeof(2) == 15 * 8
+    assert C.sizeof(L.StatsC) == lib.nvl_sizeof(2) == 16 * 8
     assert C.sizeof(L.SamplingParamsC) == lib.nvl_sizeof(3) == 16
     assert [n for n, _ in L.ModelConfigC._fields_][:3] == ["vocab_size", "hidden", "num_layers"]
     assert len(L.SLOTS) == 33 and L.SLOT_ID["moe_out"] == 24 and L.SLOT_ID["mamba_out_proj"] == 32      # NVL_T_COUNT

@@ -316,3 +316,38 @@ def test_large_decode_batch_matches_oracle(gpu, oracle, family, nseq):
             gpu.lib().nvl_set_tuning(13, old13)
         assert rel_err(got, want) <= TOL["bf16"], f"key 11 = {chunk_max}, key 13 = {interleave}"
     hm.close()
+
+
+@pytest.mark.parametrize("family", ["llama", "granite_moe", "gpt2"])
+def test_graph_replayed_decode_is_bit_identical_to_eager(gpu, oracle, family):
+    """Decode passes are captured into a hipGraph the second time their launch configuration is seen and replayed from
+    then on (stepwise nvl_forward: upload + ~85 launches + download as one hipGraphLaunch; fused loop: one graph per
+    step).  Same kernels, same arguments: logits and tokens must be bit-identical to the eager launches (key 21 = 0)."""
+    cfg, om, hm = build(gpu, oracle, family, "bf16")
+    r = np.random.default_rng(31)
+    prompts = [r.integers(0, cfg["vocab_size"], n).tolist() for n in (40, 7, 19)]
+    steps = 14
+
+    def run(graphs_on):
+        old = gpu.lib().nvl_set_tuning(21, int(graphs_on))
+        try:
+            hm.reset_stats()
+            for i in range(3):
+                hm.seq_reset(i)
+            lg, am = hm.forward_batch([0, 1, 2], prompts, [0, 0, 0])
+            out = [lg.copy()]
+            pos = [len(p) for p in prompts]
+            for _ in range(steps):                                     # stepwise: what ModelRunner.Run does
+                lg, am2 = hm.forward_batch([0, 1, 2], [[int(t)] for t in am], pos)
+                out.append(lg.copy()); am = am2; pos = [p + 1 for p in pos]
+            fused = hm.decode_greedy([0, 1, 2], am, steps)             # the fused loop on top of the same caches
+            return out, fused, hm.stats()["graph_replays"]
+        finally:
+            gpu.lib().nvl_set_tuning(21, old)
+    eager, fused_e, n_e = run(False)
+    graph, fused_g, n_g = run(True)
+    assert n_e == 0 and n_g >= 2 * (steps - 3)
+    for a, b in zip(eager, graph):
+        assert np.array_equal(a, b)
+    assert np.array_equal(fused_e, fused_g)
+    hm.close()
