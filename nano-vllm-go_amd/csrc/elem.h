@@ -546,6 +546,42 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const float* __restrict_
     moe_route_row(router_logits + (int64_t)r * ld, E, top_k, lane, expert_ids + (int64_t)r * top_k, expert_w + (int64_t)r * top_k);
 }
 
+// Decode ("dense-masked" MoE form, gemm.h GemmArgs::moe_gate): the routing result as a dense [rows][E] matrix of
+// renormalised weights, 0 for the experts a token did not pick.  One wave per token, many workgroups.
+__global__ __launch_bounds__(256) void moe_gate_kernel(const float* __restrict__ router_logits, int ld, int rows, int E,
+                                                       int top_k, float* __restrict__ gate) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* logits_row = router_logits + (int64_t)r * ld;
+    const float v = (lane < E) ? logits_row[lane] : -INFINITY;
+    const float mx = wave_max(v);
+    const float e = (lane < E) ? expf(v - mx) : 0.f;
+    const float s = wave_sum(e);
+    const float prob = (lane < E) ? e / s : -1.f;
+    int rank = 0;                                   // as moe_route_row: larger first, ties to the lower index
+    const int pbits = __builtin_bit_cast(int, prob);
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+        const float pj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pbits, j));
+        rank += (pj > prob || (pj == prob && j < lane)) ? 1 : 0;
+    }
+    float wsum = 0.f;
+    for (int k = 0; k < top_k; k++) {               // moe.go:89-92: fp32 sum in rank order
+        const int src = __ffsll((unsigned long long)__ballot(rank == k)) - 1;
+        wsum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(pbits, src));
+    }
+    if (lane < E) gate[(int64_t)r * E + lane] = rank < top_k ? prob / wsum : 0.f;      // moe.go:103
+}
+// W_down of all experts concatenated along K, fragment-major [H_pad][E * I]: block (nt, e * I/32 + kb) = block (nt, kb) of
+// expert e's [H][I] matrix.  grid (H / 16, E); one-off at finalize.
+__global__ __launch_bounds__(256) void moe_cat_down_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int H, int I, int E) {
+    const int nt = blockIdx.x, e = blockIdx.y, kbs = I >> 5;
+    const bf16x8* s8 = (const bf16x8*)(src + ((int64_t)e * H * I + (int64_t)nt * kbs * 512));
+    bf16x8* d8 = (bf16x8*)(dst + ((int64_t)nt * E * kbs + (int64_t)e * kbs) * 512);
+    for (int i = threadIdx.x; i < kbs * 64; i += 256) d8[i] = s8[i];
+}
+
 // Small batches (decode: rows * top_k <= MOE_PLAN_MAX_PAIRS): routing, the per-expert histogram, the segment scan with
 // the grouped GEMM's tile map, and the scatter of (token, expert) pairs into expert order — moe_route / hist / scan /
 // scatter above and the memset of the counters — as ONE single-workgroup launch.

@@ -96,7 +96,22 @@ struct GemmArgs {
     const float* rs_in;     // consumer: the same buffer
     int rs_tiles;
     float rs_inv_h, rs_eps;
+    // MoE decode, "dense-masked" form (decode kernels only, M <= 64).  All experts are ONE projection each way:
+    //   up   W = [E * 2I][H] (the experts' interleaved gate|up rows back to back), output column f belongs to expert f / I;
+    //   down W = [H][E * I] (the experts concatenated along K), a wave's K range lies inside ONE expert.
+    // moe_gate [M][E] holds the renormalised routing weight of (token, expert), 0 when the token did not pick the expert.
+    // A workgroup (up) / wave (down) whose expert no token of the batch picked returns before it loads a weight byte, so
+    // only the touched experts are streamed; the up epilogue multiplies row m by moe_gate[m][e], which makes the down
+    // projection's K reduction the weighted combine itself (moe.go:105-120) — no sort, no plan, no combine launch.
+    const float* moe_gate;
+    int moe_E, moe_I;
 };
+// does any row of the batch (M <= 64: one per lane) route to expert e?  Call with all 64 lanes active.
+__device__ __forceinline__ bool moe_expert_live(const GemmArgs& p, int e) {
+    const int lane = threadIdx.x & 63;
+    const float g = lane < p.M ? p.moe_gate[lane * p.moe_E + e] : 0.f;
+    return __any(g != 0.f);
+}
 
 __device__ __forceinline__ float silu_f(float g) { return g / (1.0f + __expf(-g)); }
 __device__ __forceinline__ float gelu_tanh_f(float x) {
@@ -174,6 +189,7 @@ __device__ __forceinline__ void epilogue_swiglu4(const GemmArgs& p, int m, int f
     f32x4 v;
 #pragma unroll
     for (int r = 0; r < 4; r++) v[r] = silu_f(g[r]) * u[r];
+    if (p.moe_gate) v *= p.moe_gate[m * p.moe_E + f / p.moe_I];      // routing weight of (token, expert); 0 = not routed
     act_store4<OutT>((OutT*)p.C, (int64_t)p.c_row0 + m, f, p.ldc, v);
 }
 
@@ -593,8 +609,12 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     const int nslices = p.m_split ? 1 : gridDim.y, slice = p.m_split ? 0 : blockIdx.y;
     const int nparts = ksplit * nslices, part = slice * ksplit + kw;
     const int nks = p.K >> 5, q = nks / nparts, rr = nks - q * nparts;
-    const int my_steps = q + (part < rr ? 1 : 0);
+    int my_steps = q + (part < rr ? 1 : 0);
     const int ks0 = part * q + (part < rr ? part : rr);   // first k-step of this wave
+    if (p.moe_gate) {      // MoE decode: stream only the experts some token of the batch picked
+        if (EPI == EPI_SWIGLU) { if (!moe_expert_live(p, (nt0 * 16) / (2 * p.moe_I))) return; }          // (whole workgroup: uniform)
+        else if (!moe_expert_live(p, (ks0 * 32) / p.moe_I)) my_steps = 0;                                 // this wave adds zero
+    }
 
     const bf16_t* wp = (const bf16_t*)p.W + (((int64_t)(nt0 + tile) * (p.K >> 5) + ks0) * 64 + lane) * 8;
     const bf16_t* xp[MT];
@@ -784,6 +804,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
     if constexpr (PASSES) skinny_pass_remap(p, bx);     // (its own instantiation: rewriting the arguments costs the
                                                         // single-group kernels a few scratch dwords otherwise)
     const int nt0 = bx * NTB;
+    if (p.moe_gate && !moe_expert_live(p, (nt0 * 16) / (2 * p.moe_I))) return;      // MoE decode: untouched expert (uniform)
     const int nks = p.K >> 5, q = nks / ksplit, rr = nks - q * ksplit;
     const int my_steps = q + (kw < rr ? 1 : 0);
     const int ks0 = kw * q + (kw < rr ? kw : rr);
@@ -929,6 +950,10 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
     if (g_force_ksplit) ksplit = g_force_ksplit;
     else while (ksplit > 1 && (int64_t)nblocks * KS * NTW * ksplit > g_narrow_waves) ksplit >>= 1;
     while (ksplit > 1 && ((a.K >> 5) / (ksplit * KS) < U || ksplit * NTW > 16)) ksplit >>= 1;   // >= one block of U k-steps per wave
+    if (a.moe_gate && EPI == EPI_RESID) {      // MoE down: every wave's K range is exactly one expert (the skip test needs it)
+        ksplit = a.moe_E / KS;
+        if (ksplit < 1 || ksplit * KS != a.moe_E || ksplit > 16 || (a.moe_I >> 5) < 1) return false;
+    }
     if (a.K % 32 != 0) return false;
     const size_t lds = (size_t)NTW * ksplit * MT * 64 * 16;
     if (a.m_passes > 1 && (nblocks % 8 != 0 || KS != 1)) return launch_skinny_passes_serial<EPI, OutT>(st, a);

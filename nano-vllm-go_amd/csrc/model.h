@@ -31,6 +31,7 @@ struct LayerW {
     void* w_qkv = nullptr; int n_qkv = 0; float* b_qkv = nullptr;
     void* w1 = nullptr; int n1 = 0;      // fused rows (2F for SwiGLU, F for GELU)
     void* moe_in = nullptr;              // [E][2I (interleaved in bf16 mode)][H]
+    void* moe_out_cat = nullptr;         // bf16: W_down of all experts along K, [H_pad][E*I] (decode "dense-masked" form)
     bool mamba = false;                  // a Mamba2 block (attention tensors absent); index among the Mamba2 layers
     int mamba_idx = -1;
 };
@@ -119,6 +120,9 @@ struct nvl_model {
     int32_t* expert_ids = nullptr; float* expert_w = nullptr;
     int32_t *seg_start = nullptr, *perm_token = nullptr, *slot_of = nullptr;
     float* moe_eo = nullptr;          // [Mmax*k][H]
+    float* moe_gate = nullptr;        // decode: [64][E] routing weights (0 = not routed)
+    void* moe_hall = nullptr;         // decode: bf16 [64][E*I] gate-weighted SwiGLU outputs of every touched expert
+    float* moe_part = nullptr;        // decode: [MOE_DOWN_SLICES][64][H] K-slice partials of the down projection
     void* moe_xg = nullptr;           // bf16: the normed rows in expert order, fragment-major [round_up(Mmax*k, 64)][H] (prefill)
     int32_t *moe_counts = nullptr, *moe_cursor = nullptr, *moe_tile_map = nullptr, *moe_n_mtiles = nullptr;
     // decode split-K: partial slices of the last residual GEMM, consumed by the next norm launch

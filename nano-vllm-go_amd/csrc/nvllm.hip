@@ -17,6 +17,8 @@
 using namespace nvl;
 
 static thread_local std::string g_create_err;
+constexpr int MOE_DOWN_SLICES = 16;   // at most this many K slices (workgroups per column tile) in the dense-masked MoE down projection
+static inline int moe_down_slices(int E) { int s = MOE_DOWN_SLICES; while (s > 1 && E % s) s--; return s; }   // a whole number of experts per slice
 
 namespace {
 
@@ -297,7 +299,7 @@ extern "C" void nvl_destroy(nvl_model* m) {
     for (int k = 0; k < NVL_T_COUNT; k++) dfree(m->g[k].p);
     for (auto& l : m->layers) {
         for (int k = 0; k < NVL_T_COUNT; k++) dfree(l.t[k].p);
-        dfree(l.w_qkv); dfree(l.b_qkv); dfree(l.w1); dfree(l.moe_in);
+        dfree(l.w_qkv); dfree(l.b_qkv); dfree(l.w1); dfree(l.moe_in); dfree(l.moe_out_cat);
     }
     if (m->lm_head && m->lm_head != m->g[NVL_T_TOK_EMB].p && m->lm_head != m->g[NVL_T_LM_HEAD].p) dfree(m->lm_head);
     dfree(m->rope_cos); dfree(m->rope_sin); dfree(m->kcache); dfree(m->vcache);
@@ -305,6 +307,7 @@ extern "C" void nvl_destroy(nvl_model* m) {
     dfree(m->xn_last); dfree(m->logits); dfree(m->argmax_dev); dfree(m->argmax_pval); dfree(m->argmax_pidx); dfree(m->router_logits); dfree(m->expert_ids);
     dfree(m->expert_w); dfree(m->seg_start); dfree(m->moe_counts); dfree(m->moe_cursor); dfree(m->moe_tile_map); dfree(m->moe_n_mtiles); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo); dfree(m->moe_xg);
     dfree(m->meta_dev); dfree(m->hidden); dfree(m->sk_part); dfree(m->tp_part); dfree(m->ring); dfree(m->rs_part);
+    dfree(m->moe_gate); dfree(m->moe_hall); dfree(m->moe_part);
     clear_graphs(m);
     if (m->am_host) (void)hipHostFree(m->am_host);
     dfree(m->ring_pos0);
@@ -662,9 +665,20 @@ extern "C" int nvl_finalize(nvl_model* m) {
                     auto one = swiglu_interleave(I, e * 2 * I);
                     idx.insert(idx.end(), one.begin(), one.end());
                 }
-                l.moe_in = dmalloc_bytes(E * 2 * I * H * (int64_t)m->wsize);
+                l.moe_in = dmalloc_bytes(round_up(E * 2 * I, W_ROW_PAD) * H * (int64_t)m->wsize);   // (+ zero pad rows: the decode kernels read whole tiles)
+                NVL_HIP(hipMemsetAsync(l.moe_in, 0, (size_t)(round_up(E * 2 * I, W_ROW_PAD) * H) * m->wsize, m->stream));
                 gather_rows(m, l.t[NVL_T_MOE_IN].p, idx, l.moe_in, H);
                 dfree(l.t[NVL_T_MOE_IN].p); l.t[NVL_T_MOE_IN].p = nullptr;
+                if (I % 32 == 0 && H % 16 == 0 && E <= 64 && E / moe_down_slices((int)E) <= 16) {
+                    // decode form: the experts' down matrices side by side along K
+                    const int64_t hp = round_up(H, W_ROW_PAD);
+                    l.moe_out_cat = dmalloc_bytes(hp * E * I * 2);
+                    NVL_HIP(hipMemsetAsync(l.moe_out_cat, 0, (size_t)(hp * E * I) * 2, m->stream));
+                    hipLaunchKernelGGL(moe_cat_down_kernel, dim3((unsigned)(H / 16), (unsigned)E), dim3(256), 0, m->stream,
+                                       (const bf16_t*)l.t[NVL_T_MOE_OUT].p, (bf16_t*)l.moe_out_cat, (int)H, (int)I, (int)E);
+                    NVL_HIP(hipGetLastError());
+                    NVL_HIP(hipStreamSynchronize(m->stream));
+                }
             } else {
                 l.moe_in = l.t[NVL_T_MOE_IN].p; l.t[NVL_T_MOE_IN].p = nullptr;
             }
@@ -758,6 +772,12 @@ extern "C" int nvl_finalize(nvl_model* m) {
         m->slot_of = dmalloc<int32_t>(Mmax * k);
         m->moe_eo = dmalloc<float>(Mmax * k * H);
         if (!m->f32) m->moe_xg = dmalloc_bytes(round_up(Mmax * k, 64) * H * 2);
+        if (!m->f32) {
+            m->moe_gate = dmalloc<float>(64 * (int64_t)c.num_experts);
+            m->moe_hall = dmalloc_bytes(64 * (int64_t)c.num_experts * m->F * 2);
+            NVL_HIP(hipMemsetAsync(m->moe_hall, 0, (size_t)(64 * (int64_t)c.num_experts * m->F) * 2, m->stream));
+            m->moe_part = dmalloc<float>((int64_t)MOE_DOWN_SLICES * 64 * H);
+        }
     }
     if (m->n_mamba) {
         m->ssm_layer_stride = (int64_t)m->m_nh * m->m_hd * m->m_ss;
@@ -1099,6 +1119,7 @@ void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
 // `slices` workgroups per column block so that all 256 CUs stream weights (a 2048-column projection has
 // only 128 column blocks), and leave the add to the norm kernel that always follows (PendingResid).
 static int g_qkv_store_max_m = 256;   // nvl_set_tuning key 18: largest prefill batch whose QKV projection runs as decode-form groups + rope_kv_kernel
+static int g_moe_dense = 1;    // nvl_set_tuning key 22: decode MoE as two dense-masked projections (gemm.h moe_gate); 0 = sort + grouped GEMMs
 static int g_moe_deep = 1;     // nvl_set_tuning key 19: four-stage grouped GEMM for decode-sized MoE batches (0 = two stages)
 static int g_moe_bm = 0;       // nvl_set_tuning key 17: m-tile rows of the grouped MoE GEMMs (0 / 128: 128, 256)
 static int g_moe_gather = 1;   // nvl_set_tuning key 16: prefill MoE gathers the token rows into expert order before the grouped GEMM (0 = per-lane gather inside it)
@@ -1186,6 +1207,28 @@ void moe(nvl_model* m, const LayerW& l, int M) {
     const double e_touch = (double)std::min(E, pairs);
     m->site = KS_MOE_ROUTER;
     gemm(m, EPI_STORE, true, mk(m->xn, H, l.t[NVL_T_ROUTER].p, m->router_logits, 128, nullptr, 1.f, M, E, H));
+    // Decode: the dense-masked form (gemm.h GemmArgs::moe_gate).  Routing weights as a dense [M][E] matrix, then all experts
+    // as ONE weight-streaming projection each way; untouched experts are skipped inside the kernels, the gate weight in the up
+    // epilogue turns the down projection's K reduction into the weighted combine, its K slices are summed by the next norm.
+    if (!m->f32 && M <= 64 && g_moe_dense && l.moe_out_cat && m->moe_part && !m->keep_hidden && m->pending_slices == 0 &&
+        H % 4 == 0 && H <= 1024 * NORM_ROW_MAXCH && g_force_tile == 0) {
+        {
+            KScope ks(m, KC_OTHER, 0, KS_MOE_PLAN, (double)M * (128 + E) * 4.0);
+            hipLaunchKernelGGL(moe_gate_kernel, dim3(cdiv(M, 4)), dim3(256), 0, m->stream, m->router_logits, 128, M, E, k, m->moe_gate);
+            NVL_HIP(hipGetLastError());
+        }
+        GemmArgs a = mk(m->xn, H, l.moe_in, m->moe_hall, E * I, nullptr, 1.f, M, E * 2 * I, H);
+        a.moe_gate = m->moe_gate; a.moe_E = E; a.moe_I = I;
+        m->site = KS_MOE_UP; m->site_bytes = (e_touch * 2 * I * H + (double)M * H + e_touch * M * I) * (double)m->wsize;
+        gemm(m, EPI_SWIGLU, false, a, 2.0 * pairs * 2 * I * H);
+        GemmArgs d = mk(m->moe_hall, E * I, l.moe_out_cat, m->x, H, nullptr, 1.f, M, H, E * I);
+        const int nsl = moe_down_slices(E);
+        d.moe_gate = m->moe_gate; d.moe_E = E; d.moe_I = I; d.sk_part = m->moe_part; d.sk_slices = nsl;
+        m->site = KS_MOE_DOWN; m->site_bytes = (e_touch * H * I + e_touch * M * I) * (double)m->wsize + (double)nsl * M * H * 4.0;
+        gemm(m, EPI_RESID, true, d, 2.0 * pairs * H * I);
+        m->pending_part = m->moe_part; m->pending_slices = nsl; m->pending_rows = M; m->pending_alpha = m->resid_alpha;
+        return;
+    }
     // decode-sized batches: one planning launch, and the weighted combine rides on the norm that follows
     const bool small = !m->f32 && M <= 64 && pairs <= MOE_PLAN_MAX_PAIRS && E <= MOE_PLAN_MAX_E && g_moe_small;
     // m-tile height of the grouped GEMMs: 128 rows; the 256x128 three-stage instance stays a tuning option (Granite-1B,
