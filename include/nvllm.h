@@ -185,6 +185,14 @@ void nvl_destroy(nvl_model* m);
 int nvl_tp_get_unique_id(void* id_out, int bytes);
 int nvl_tp_init(nvl_model* m, const void* id, int bytes);
 int nvl_tp_attach_local(nvl_model** models, int n);
+/* Hand-written all-reduce over the xGMI mesh (csrc/tp_p2p.h) in place of ncclAllReduce: one-shot direct peer stores for
+ * decode-sized payloads, reduce-scatter + all-gather on the mesh for prefill-sized ones, bf16 payload with fp32
+ * accumulation in the bf16 mode, the residual add fused.  One process per GPU: every rank exports the IPC handle of its
+ * comm buffer (64 bytes, after nvl_finalize), the host gathers the tp_size handles in rank order by whatever channel it has,
+ * and every rank attaches them.  Both calls are collective in that sense.  RCCL (nvl_tp_init) stays available and is used
+ * when no peer buffers are attached. */
+int nvl_tp_p2p_export(nvl_model* m, void* handle_out, int bytes);                 /* bytes >= 64 */
+int nvl_tp_p2p_attach(nvl_model* m, const void* handles, int bytes_per_handle);   /* tp_size handles, rank order */
 
 /* ---- sequences: replace map[int64]*KVCache (tensor_model_runner.go:11-18,59-68,100-112) ---- */
 int nvl_seq_open(nvl_model* m, int64_t seq_id);     /* get-or-create a KV slot                     */

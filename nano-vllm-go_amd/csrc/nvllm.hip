@@ -307,6 +307,8 @@ extern "C" void nvl_destroy(nvl_model* m) {
     dfree(m->xn_last); dfree(m->logits); dfree(m->argmax_dev); dfree(m->argmax_pval); dfree(m->argmax_pidx); dfree(m->router_logits); dfree(m->expert_ids);
     dfree(m->expert_w); dfree(m->seg_start); dfree(m->moe_counts); dfree(m->moe_cursor); dfree(m->moe_tile_map); dfree(m->moe_n_mtiles); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo); dfree(m->moe_xg);
     dfree(m->meta_dev); dfree(m->hidden); dfree(m->sk_part); dfree(m->tp_part); dfree(m->ring); dfree(m->rs_part);
+    for (int r = 0; r < 8; r++) if (m->p2p_peer[r] && m->p2p_peer[r] != m->p2p_buf) (void)hipIpcCloseMemHandle(m->p2p_peer[r]);
+    dfree(m->p2p_buf);
     dfree(m->moe_gate); dfree(m->moe_hall); dfree(m->moe_part);
     clear_graphs(m);
     if (m->am_host) (void)hipHostFree(m->am_host);
@@ -830,6 +832,57 @@ extern "C" int nvl_tp_init(nvl_model* m, const void* id_in, int bytes) {
     return NVL_OK;
     NVL_CATCH(m)
 }
+namespace {
+constexpr int P2P_ONESHOT_CAP_ROWS = 64;
+void p2p_alloc(nvl_model* m) {
+    if (m->p2p_buf) return;
+    const int64_t esz = m->f32 ? 4 : 2, T = m->tp;
+    const int64_t cap = (int64_t)m->opts.max_batch_tokens * m->H;
+    m->p2p_in1_stride = (int64_t)P2P_ONESHOT_CAP_ROWS * m->H;
+    m->p2p_in2_stride = round_up(cdiv(cap, T), 4);
+    m->p2p_res_stride = round_up(cap, 4);
+    m->p2p_off_in1 = 1024;
+    m->p2p_off_in2 = round_up(m->p2p_off_in1 + 2 * T * m->p2p_in1_stride * esz, 256);
+    m->p2p_off_res = round_up(m->p2p_off_in2 + 2 * T * m->p2p_in2_stride * esz, 256);
+    m->p2p_bytes = (size_t)round_up(m->p2p_off_res + 2 * m->p2p_res_stride * esz, 256);
+    void* p = nullptr;
+    NVL_HIP(hipExtMallocWithFlags(&p, m->p2p_bytes, hipDeviceMallocUncached));     // coherent across GPUs: peers write it, we poll it
+    m->p2p_buf = (char*)p;
+    NVL_HIP(hipMemset(m->p2p_buf, 0, m->p2p_bytes));
+}
+}  // namespace
+extern "C" int nvl_tp_p2p_export(nvl_model* m, void* handle_out, int bytes) {
+    if (!m || !handle_out || bytes < (int)sizeof(hipIpcMemHandle_t)) return fail(m, NVL_ERR_INVALID, "nvl_tp_p2p_export: need a 64-byte buffer");
+    if (!m->finalized) return fail(m, NVL_ERR_STATE, "nvl_tp_p2p_export: finalize the model first");
+    if (m->tp < 2) return fail(m, NVL_ERR_STATE, "nvl_tp_p2p_export: the model is not tensor-parallel");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    p2p_alloc(m);
+    hipIpcMemHandle_t h;
+    NVL_HIP(hipIpcGetMemHandle(&h, m->p2p_buf));
+    memcpy(handle_out, &h, sizeof h);
+    return NVL_OK;
+    NVL_CATCH(m)
+}
+extern "C" int nvl_tp_p2p_attach(nvl_model* m, const void* handles, int bytes_per_handle) {
+    if (!m || !handles || bytes_per_handle < (int)sizeof(hipIpcMemHandle_t)) return fail(m, NVL_ERR_INVALID, "nvl_tp_p2p_attach: bad arguments");
+    if (!m->p2p_buf) return fail(m, NVL_ERR_STATE, "nvl_tp_p2p_attach: call nvl_tp_p2p_export first");
+    if (m->p2p_ready) return fail(m, NVL_ERR_STATE, "nvl_tp_p2p_attach: already attached");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    for (int r = 0; r < m->tp; r++) {
+        if (r == m->tp_rank) { m->p2p_peer[r] = m->p2p_buf; continue; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char*)handles + (size_t)r * bytes_per_handle, sizeof h);
+        void* p = nullptr;
+        NVL_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        m->p2p_peer[r] = (char*)p;
+    }
+    m->p2p_ready = true;
+    return NVL_OK;
+    NVL_CATCH(m)
+}
+
 extern "C" int nvl_tp_attach_local(nvl_model** models, int n) {
     if (!models || n < 1 || n > 8) return fail(nullptr, NVL_ERR_INVALID, "nvl_tp_attach_local: bad arguments");
     bool seen[8] = {false};
@@ -973,6 +1026,7 @@ void norm(nvl_model* m, float* x, const int32_t* rows_idx, const DevTensor& w, c
     NVL_HIP(hipGetLastError());
 }
 
+static int g_p2p_oneshot_rows = 64;   // nvl_set_tuning key 23: payloads of up to this many rows take the one-shot all-reduce
 static int g_use_graphs = 1;   // nvl_set_tuning key 21: hipGraph replay of decode passes (0 = every launch eager)
 static int g_tune_epoch = 0;   // bumped by every nvl_set_tuning: captured graphs bake the tuning in (part of their key)
 static int g_attn_nw = 0;      // nvl_set_tuning key 15: waves per decode-attention workgroup (0 = from the context length, 2, 4, 8)
@@ -1114,6 +1168,41 @@ void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
     }
 }
 
+// x += alpha * sum over the tensor-parallel ranks of `part` [M][N], by direct peer stores over the xGMI mesh (tp_p2p.h)
+void tp_p2p_allreduce_resid(nvl_model* m, const float* part, int M, int N, float alpha) {
+    const int64_t count = (int64_t)M * N;
+    if (count % 4) throw std::runtime_error("tp p2p: payload must be a multiple of 4 elements");
+    P2PArgs a{};
+    a.T = m->tp; a.rank = m->tp_rank; a.parity = (int)(m->p2p_calls & 1); m->p2p_calls++;
+    a.count = count; a.part = part; a.x = m->x; a.alpha = alpha;
+    for (int r = 0; r < m->tp; r++) a.peer[r] = m->p2p_peer[r];
+    a.off_ctr = 0; a.off_err = 960; a.off_in1 = m->p2p_off_in1; a.off_in2 = m->p2p_off_in2; a.off_res = m->p2p_off_res;
+    a.in1_stride = m->p2p_in1_stride; a.in2_stride = m->p2p_in2_stride; a.res_stride = m->p2p_res_stride;
+    a.spin_limit = 4000000;                                   // x ~1 us of s_sleep: a few seconds, then fail instead of hanging
+    const int nwg = (int)std::min<int64_t>(cdiv(count, 1024), 512);
+    KScope ks(m, KC_OTHER, 0, KS_ALLREDUCE, (double)count * (m->f32 ? 4.0 : 2.0) * 2.0);
+    const bool oneshot = M <= g_p2p_oneshot_rows && M <= P2P_ONESHOT_CAP_ROWS;
+#define NVL_P2P(PT)                                                                                                    \
+    do {                                                                                                               \
+        if (oneshot) {                                                                                                 \
+            hipLaunchKernelGGL((p2p_oneshot_send_kernel<PT>), dim3(nwg), dim3(256), 0, m->stream, a);                  \
+            a.target = (m->p2p_expect[a.parity][0] += (unsigned long long)a.T * nwg);                                  \
+            hipLaunchKernelGGL((p2p_oneshot_apply_kernel<PT>), dim3(nwg), dim3(256), 0, m->stream, a);                 \
+        } else {                                                                                                       \
+            a.chunk = round_up(cdiv(count, a.T), 4);                                                                   \
+            const int nwg2 = (int)std::min<int64_t>(cdiv(a.chunk, 1024), 512);                                         \
+            hipLaunchKernelGGL((p2p_rs_send_kernel<PT>), dim3(nwg), dim3(256), 0, m->stream, a);                       \
+            a.target = (m->p2p_expect[a.parity][1] += (unsigned long long)a.T * nwg);                                  \
+            hipLaunchKernelGGL((p2p_rs_reduce_bcast_kernel<PT>), dim3(nwg2), dim3(256), 0, m->stream, a);              \
+            a.target = (m->p2p_expect[a.parity][2] += (unsigned long long)a.T * nwg2);                                 \
+            hipLaunchKernelGGL((p2p_ag_apply_kernel<PT>), dim3(nwg), dim3(256), 0, m->stream, a);                      \
+        }                                                                                                              \
+    } while (0)
+    if (m->f32) NVL_P2P(float); else NVL_P2P(bf16_t);
+#undef NVL_P2P
+    NVL_HIP(hipGetLastError());
+}
+
 // Residual projection (O projection / W2): x += alpha * (A·W^T + bias)   (generic_model.go:320-326,383-389).
 // Prefill and the fp32 mode fuse the add into the GEMM epilogue.  Decode-sized batches split K over
 // `slices` workgroups per column block so that all 256 CUs stream weights (a 2048-column projection has
@@ -1137,6 +1226,7 @@ void resid_gemm(nvl_model* m, const void* A, int lda, const void* W, const float
         // row-parallel projection: this rank holds a K slice -> fp32 partial [M][N] (the bias lives on rank 0 only),
         // all-reduce over the tensor-parallel group, then the residual add (folded into the next norm for decode)
         gemm(m, EPI_STORE, true, mk(A, lda, W, m->tp_part, N, bias, 1.f, M, N, K));
+        if (m->p2p_ready) { tp_p2p_allreduce_resid(m, m->tp_part, M, N, alpha); return; }     // sum + residual add in one go
         tp_allreduce(m, m->tp_part, (int64_t)M * N);
         if (!m->f32 && M <= 64 && !m->keep_hidden && m->pending_slices == 0) {
             m->pending_part = m->tp_part; m->pending_slices = 1; m->pending_rows = M; m->pending_alpha = alpha;
@@ -1199,19 +1289,31 @@ void ffn_up(nvl_model* m, const LayerW& l, int M, bool deferred_norm = false) {
 // the (token, rank) pairs by expert -> ONE grouped gate/up GEMM and ONE grouped down GEMM over all experts
 // (m-tiles mapped to (expert, row segment) by a device table; token rows gathered by per-lane source address)
 // -> combine in rank order into x (with the residual multiplier).  The fp32 parity mode launches per expert.
-void moe(nvl_model* m, const LayerW& l, int M) {
+// can this call take the decode ("dense-masked") MoE form?  (also decides whether the O projection may carry the FFN norm)
+bool moe_dense_ok(const nvl_model* m, const LayerW& l, int M) {
+    return !m->f32 && M <= 64 && g_moe_dense && l.moe_out_cat && m->moe_part && !m->keep_hidden && m->H % 4 == 0 &&
+           m->H <= 1024 * NORM_ROW_MAXCH && g_force_tile == 0;
+}
+// deferred_norm: m->xn holds xn_raw = bf16(x * w_norm) and m->rs_part the x^2 partials (the O projection carried the FFN
+// norm): the router and the expert-up projection scale their accumulators by rstd[m] instead of reading a normed operand
+void moe(nvl_model* m, const LayerW& l, int M, bool deferred_norm = false) {
     const nvl_model_config& c = m->cfg;
     const int E = c.num_experts, k = c.num_experts_per_tok, I = m->F, H = m->H;
     const int pairs = M * k;
     // algorithmic weight bytes of the expert GEMMs: the experts a batch of `pairs` (token, rank) pairs can touch, once
     const double e_touch = (double)std::min(E, pairs);
     m->site = KS_MOE_ROUTER;
-    gemm(m, EPI_STORE, true, mk(m->xn, H, l.t[NVL_T_ROUTER].p, m->router_logits, 128, nullptr, 1.f, M, E, H));
+    {
+        GemmArgs ar = mk(m->xn, H, l.t[NVL_T_ROUTER].p, m->router_logits, 128, nullptr, 1.f, M, E, H);
+        if (deferred_norm) set_deferred_in(m, ar);
+        gemm(m, EPI_STORE, true, ar);
+    }
     // Decode: the dense-masked form (gemm.h GemmArgs::moe_gate).  Routing weights as a dense [M][E] matrix, then all experts
     // as ONE weight-streaming projection each way; untouched experts are skipped inside the kernels, the gate weight in the up
     // epilogue turns the down projection's K reduction into the weighted combine, its K slices are summed by the next norm.
-    if (!m->f32 && M <= 64 && g_moe_dense && l.moe_out_cat && m->moe_part && !m->keep_hidden && m->pending_slices == 0 &&
-        H % 4 == 0 && H <= 1024 * NORM_ROW_MAXCH && g_force_tile == 0) {
+    if (deferred_norm && !(moe_dense_ok(m, l, M) && m->pending_slices == 0))
+        throw std::runtime_error("moe: a deferred FFN norm needs the dense-masked decode form");
+    if (moe_dense_ok(m, l, M) && m->pending_slices == 0) {
         {
             KScope ks(m, KC_OTHER, 0, KS_MOE_PLAN, (double)M * (128 + E) * 4.0);
             hipLaunchKernelGGL(moe_gate_kernel, dim3(cdiv(M, 4)), dim3(256), 0, m->stream, m->router_logits, 128, M, E, k, m->moe_gate);
@@ -1219,6 +1321,7 @@ void moe(nvl_model* m, const LayerW& l, int M) {
         }
         GemmArgs a = mk(m->xn, H, l.moe_in, m->moe_hall, E * I, nullptr, 1.f, M, E * 2 * I, H);
         a.moe_gate = m->moe_gate; a.moe_E = E; a.moe_I = I;
+        if (deferred_norm) set_deferred_in(m, a);
         m->site = KS_MOE_UP; m->site_bytes = (e_touch * 2 * I * H + (double)M * H + e_touch * M * I) * (double)m->wsize;
         gemm(m, EPI_SWIGLU, false, a, 2.0 * pairs * 2 * I * H);
         GemmArgs d = mk(m->moe_hall, E * I, l.moe_out_cat, m->x, H, nullptr, 1.f, M, H, E * I);
@@ -1383,6 +1486,10 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
     const bool defer_ok = g_defer_norm && !m->f32 && (M <= 64 || (M <= DEFER_MAX_M && big_decode && g_defer_norm == 1)) && !c.use_moe && m->tp == 1 && !m->tp_force && !m->keep_hidden &&
                           c.block_style == NVL_BLOCK_SEQUENTIAL && c.norm_type == NVL_NORM_RMS &&
                           c.activation_type == NVL_ACT_SWIGLU && H % 256 == 0 && m->rs_part && m->n_mamba == 0;
+    // MoE layers (decode form): only the O projection carries a norm (the FFN norm); the expert-down projection leaves
+    // K-slice partials that the next attention norm sums
+    const bool defer_moe_ok = g_defer_norm && c.use_moe && M <= 64 && m->tp == 1 && !m->tp_force && c.block_style == NVL_BLOCK_SEQUENTIAL &&
+                              c.norm_type == NVL_NORM_RMS && H % 256 == 0 && m->rs_part && m->n_mamba == 0;
     const bool all_rows = (flags & NVL_FWD_ALL_LOGITS) != 0;
     bool xn_deferred = false;       // m->xn holds xn_raw of the upcoming norm, m->rs_part its x^2 partials
     for (int li = 0; li < m->L; li++) {
@@ -1475,7 +1582,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
                        M, H, m->F);   // (only one of the two may be pending: the second one adds into x directly)
         } else {
             // decode, RMSNorm + SwiGLU: the O-projection carries the FFN norm (deferred RMSNorm, gemm.h) — one launch less
-            const bool defer = defer_ok && m->pending_slices == 0 && !l.t[NVL_T_FFN_NORM_B].present();
+            const bool defer = (defer_ok || (defer_moe_ok && moe_dense_ok(m, l, M))) && m->pending_slices == 0 && !l.t[NVL_T_FFN_NORM_B].present();
             m->site = KS_OPROJ;
             if (defer) {
                 resid_gemm(m, m->attn_out, qw, l.t[NVL_T_WO].p, bo, m->resid_alpha, M, H, qw, (const float*)l.t[NVL_T_FFN_NORM_W].p);
@@ -1484,7 +1591,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
                 norm(m, m->x, nullptr, l.t[NVL_T_FFN_NORM_W], l.t[NVL_T_FFN_NORM_B], m->xn, M);
             }
             if (c.use_moe) {
-                moe(m, l, M);
+                moe(m, l, M, defer);
             } else {
                 ffn_up(m, l, M, defer);
                 // the FFN-down projection carries the NEXT layer's attention norm, or the final norm when every row is
