@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="control-flow rehearsal of the multi-rank path on a box with ONE GPU: every rank uses device 0 and "
                          "the rendezvous/barrier/max-reduce run over gloo (the printed value is meaningless)")
+    ap.add_argument("--tp-collective", choices=["p2p", "rccl"], default="p2p",
+                    help="--tp: p2p = the hand-written all-reduce over peer-mapped buffers (csrc/tp_p2p.h; one-shot for decode, "
+                         "reduce-scatter + all-gather for prefill, residual fused); rccl = ncclAllReduce, the comparison line")
     ap.add_argument("--tune", default="", help="nvl_set_tuning overrides, e.g. 1=2 (key=value, comma separated)")
     ap.add_argument("--launch-check", action="store_true",
                     help="no GPU work: every rank joins the rendezvous (gloo), passes the barrier / max-reduce and rank 0 "
@@ -196,11 +199,18 @@ def main():
     t0 = time.time()
     host_w = gen_weights_on_device(pkg, cfg, model, torch, device, keep_host=want_cpu)
     model.finalize()
-    if tp:   # rank 0 creates the RCCL unique id, every rank joins (collective)
+    if tp and (args.tp_collective == "rccl" or world == 1) and not args.rehearse_on_one_gpu:
+        # rank 0 creates the RCCL unique id, every rank joins (collective)
         uid = [pkg.HipTransformerModel.tp_unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(uid, src=0)
         model.tp_init(uid[0])
+    elif tp:
+        # direct peer stores: every rank exports the IPC handle of its comm buffer, all ranks attach all of them
+        # (on the one-GPU rehearsal both ranks live on device 0: RCCL refuses two ranks on one device, this path does not)
+        handles = [None] * world
+        dist.all_gather_object(handles, model.tp_p2p_export())
+        model.tp_p2p_attach(handles)
     t_load = time.time() - t0
 
     # seed 1234 + cfg_idx; data parallel: +rank (own sequences); tensor parallel: same batch on all ranks
@@ -263,9 +273,10 @@ def main():
     # both phases (events in the decode loop would cost the timed value a few percent).  nvl_get_kernel_stats: per
     # launch site, launches, device time and algorithmic work.
     kernels = []
-    if rank == 0:
+    if rank == 0 or tp:                  # (a tensor-parallel group steps together: every rank runs the extra step)
         model.reset_stats()
         one_step(True, True)
+    if rank == 0:
         ks = model.kernel_stats()
         tot_ms = sum(k["ms"] for k in ks) or 1.0
         for k in sorted(ks, key=lambda k: -k["ms"]):
@@ -332,7 +343,8 @@ def main():
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic (seeded random weights at the model's "
         "shapes, uniform random token ids)",
         "config": {"workload": f"{args.model}: {B} seqs/GPU x {S} prompt tokens prefill + {G} greedy decode steps ({args.decode})",
-                   "batch_per_gpu": B, "prompt_len": S, "gen_len": G, "parallelism": (f"tp{world} (column/row-parallel, RCCL all-reduce)" if tp else f"dp{world} over sequences")},
+                   "batch_per_gpu": B, "prompt_len": S, "gen_len": G, "parallelism": (f"tp{world} (column/row-parallel, " + ("RCCL all-reduce)" if (args.tp_collective == "rccl" or world == 1) and not args.rehearse_on_one_gpu
+                                                                                     else "P2P all-reduce over peer-mapped buffers)") if tp else f"dp{world} over sequences")},
         "prefill_tokens_per_s": round(nrep * B * S * args.steps / pre_s, 1),
         "decode_tokens_per_s": round(nrep * B * G * args.steps / dec_s, 1),
         "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel (prefill QKV/O/FFN projections; gemm_bf16_kernel for the small LM-head GEMM)",

@@ -161,6 +161,8 @@ def lib():
     L.nvl_tp_get_unique_id.argtypes = [vp, C.c_int]
     L.nvl_tp_init.argtypes = [vp, vp, C.c_int]
     L.nvl_tp_attach_local.argtypes = [vp, C.c_int]
+    L.nvl_tp_p2p_export.argtypes = [vp, vp, C.c_int]
+    L.nvl_tp_p2p_attach.argtypes = [vp, vp, C.c_int]
     L.nvl_sizeof.argtypes = [C.c_int]
     _lib = L
     return L

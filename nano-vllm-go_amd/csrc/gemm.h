@@ -181,7 +181,7 @@ __device__ __forceinline__ float deferred_rstd(const GemmArgs& p, int m) {
     return 1.0f / sqrtf(s * p.rs_inv_h + p.rs_eps);
 }
 
-template <typename OutT>
+template <typename OutT, bool MOE = false>
 __device__ __forceinline__ void epilogue_swiglu4(const GemmArgs& p, int m, int f, f32x4 g, f32x4 u, float rstd = 1.0f) {
     // p.N counts fused rows (2F); the output has F = N/2 columns, ldc = F
     if (m >= p.M || f >= (p.N >> 1)) return;
@@ -189,7 +189,7 @@ __device__ __forceinline__ void epilogue_swiglu4(const GemmArgs& p, int m, int f
     f32x4 v;
 #pragma unroll
     for (int r = 0; r < 4; r++) v[r] = silu_f(g[r]) * u[r];
-    if (p.moe_gate) v *= p.moe_gate[m * p.moe_E + f / p.moe_I];      // routing weight of (token, expert); 0 = not routed
+    if constexpr (MOE) v *= p.moe_gate[m * p.moe_E + f / p.moe_I];      // routing weight of (token, expert); 0 = not routed
     act_store4<OutT>((OutT*)p.C, (int64_t)p.c_row0 + m, f, p.ldc, v);
 }
 
@@ -587,7 +587,7 @@ __device__ __forceinline__ void skinny_pass_remap(GemmArgs& p, int& bx) {
     }
 }
 
-template <int MT, int NTW, int U, int EPI, typename OutT, bool PASSES = false>
+template <int MT, int NTW, int U, int EPI, typename OutT, bool PASSES = false, bool MOE = false>
 __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* red = (f32x4*)smem;                       // [NTW][ksplit][MT][64]
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     const int nks = p.K >> 5, q = nks / nparts, rr = nks - q * nparts;
     int my_steps = q + (part < rr ? 1 : 0);
     const int ks0 = part * q + (part < rr ? part : rr);   // first k-step of this wave
-    if (p.moe_gate) {      // MoE decode: stream only the experts some token of the batch picked
+    if constexpr (MOE) {   // MoE decode (its own instantiation): stream only the experts some token of the batch picked
         if (EPI == EPI_SWIGLU) { if (!moe_expert_live(p, (nt0 * 16) / (2 * p.moe_I))) return; }          // (whole workgroup: uniform)
         else if (!moe_expert_live(p, (ks0 * 32) / p.moe_I)) my_steps = 0;                                 // this wave adds zero
     }
@@ -672,8 +672,8 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     if (EPI == EPI_SWIGLU) {
         for (int i = wave; i < MT; i += NTW * ksplit) {
             const int f = (nt0 >> 1) * 16 + 4 * fg;    // NTW == 2: tiles [gate 16 | up 16] of features 8*nt0..
-            epilogue_swiglu4<OutT>(p, 16 * i + fr, f, ksum(0, i), ksum(NTW - 1, i),
-                                   i == i_pre ? rstd_pre : deferred_rstd(p, 16 * i + fr));
+            epilogue_swiglu4<OutT, MOE>(p, 16 * i + fr, f, ksum(0, i), ksum(NTW - 1, i),
+                                        i == i_pre ? rstd_pre : deferred_rstd(p, 16 * i + fr));
         }
     } else if (EPI == EPI_RESID && nslices > 1) {
         // split-K across workgroups: publish the partial tile (slice 0 carries the bias); the following norm
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 // register sets of U k-steps x (NTB weight + MT activation) fragments — for K = 2048 a wave's whole slice is in
 // flight at once.  Same deterministic in-LDS K reduction and fused epilogues as the narrow form.
 // ------------------------------------------------------------------------------------------
-template <int MT, int NTB, int U, int EPI, typename OutT, bool PASSES = false>
+template <int MT, int NTB, int U, int EPI, typename OutT, bool PASSES = false, bool MOE = false>
 __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* red = (f32x4*)smem;                       // [ksplit][NTB][MT][64]
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
     if constexpr (PASSES) skinny_pass_remap(p, bx);     // (its own instantiation: rewriting the arguments costs the
                                                         // single-group kernels a few scratch dwords otherwise)
     const int nt0 = bx * NTB;
-    if (p.moe_gate && !moe_expert_live(p, (nt0 * 16) / (2 * p.moe_I))) return;      // MoE decode: untouched expert (uniform)
+    if constexpr (MOE) { if (!moe_expert_live(p, (nt0 * 16) / (2 * p.moe_I))) return; }      // MoE decode: untouched expert (uniform)
     const int nks = p.K >> 5, q = nks / ksplit, rr = nks - q * ksplit;
     const int my_steps = q + (kw < rr ? 1 : 0);
     const int ks0 = kw * q + (kw < rr ? kw : rr);
@@ -878,8 +878,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
         for (int e = kw; e < (NTB / 2) * MT; e += ksplit) {
             const int j = e / MT, i = e - j * MT;
             const int f = ((nt0 >> 1) + j) * 16 + 4 * fg;
-            epilogue_swiglu4<OutT>(p, 16 * i + fr, f, ksum(2 * j, i), ksum(2 * j + 1, i),
-                                   i == i_pre ? rstd_pre : deferred_rstd(p, 16 * i + fr));
+            epilogue_swiglu4<OutT, MOE>(p, 16 * i + fr, f, ksum(2 * j, i), ksum(2 * j + 1, i),
+                                        i == i_pre ? rstd_pre : deferred_rstd(p, 16 * i + fr));
         }
     } else {
         for (int e = kw; e < NTB * MT; e += ksplit) {
@@ -959,9 +959,18 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
     if (a.m_passes > 1 && (nblocks % 8 != 0 || KS != 1)) return launch_skinny_passes_serial<EPI, OutT>(st, a);
     dim3 grid(nblocks * (a.m_passes > 1 ? a.m_passes : 1), KS), block(NTW * ksplit * 64);
 #define NVL_SK(MTv, Uv) hipLaunchKernelGGL((gemm_skinny_bf16_kernel<MTv, NTW, Uv, EPI, OutT>), grid, block, lds, st, a)
+#define NVL_SKM(MTv, Uv) hipLaunchKernelGGL((gemm_skinny_bf16_kernel<MTv, NTW, Uv, EPI, OutT, false, true>), grid, block, lds, st, a)
+    if constexpr (EPI == EPI_SWIGLU || EPI == EPI_RESID) {
+        if (a.moe_gate) {                                 // MoE decode instantiation (expert skip + gate weight)
+            if (a.m_passes > 1) return false;
+            if (MT == 1) NVL_SKM(1, 4); else if (MT == 2) NVL_SKM(2, 4); else NVL_SKM(4, 2);
+            return true;
+        }
+    }
     if (a.m_passes > 1) hipLaunchKernelGGL((gemm_skinny_bf16_kernel<4, NTW, 2, EPI, OutT, true>), grid, block, lds, st, a);
     else if (MT == 1) NVL_SK(1, 4); else if (MT == 2) NVL_SK(2, 4); else NVL_SK(4, 2);
 #undef NVL_SK
+#undef NVL_SKM
     return true;
 }
 template <int EPI, typename OutT>
@@ -987,8 +996,22 @@ static inline bool launch_gemm_skinny_wide(hipStream_t st, const GemmArgs& a) {
         hipLaunchKernelGGL((gemm_skinny_wide_bf16_kernel<MTv, NTB, Uv, EPI, OutT, Pv>), dim3(wgs), dim3(ksplit * 64),      \
                            lds, st, a);                                                                                \
     } while (0)
+#define NVL_SKWM(MTv, Uv)                                                                                                \
+    do {                                                                                                               \
+        NVL_LDS_ATTR((gemm_skinny_wide_bf16_kernel<MTv, NTB, Uv, EPI, OutT, false, true>), 8 * NTB * MTv * 64 * 16);         \
+        hipLaunchKernelGGL((gemm_skinny_wide_bf16_kernel<MTv, NTB, Uv, EPI, OutT, false, true>), dim3(wgs), dim3(ksplit * 64), \
+                           lds, st, a);                                                                                \
+    } while (0)
+    if constexpr (EPI == EPI_SWIGLU) {
+        if (a.moe_gate) {
+            if (a.m_passes > 1) return false;
+            if (MT == 1) NVL_SKWM(1, 4); else if (MT == 2) NVL_SKWM(2, 4); else NVL_SKWM(4, 2);
+            return true;
+        }
+    }
     if (a.m_passes > 1) NVL_SKW(4, 2, true); else if (MT == 1) NVL_SKW(1, 4, false); else if (MT == 2) NVL_SKW(2, 4, false); else NVL_SKW(4, 2, false);
 #undef NVL_SKW
+#undef NVL_SKWM
     return true;
 }
 template <int EPI, typename OutT>

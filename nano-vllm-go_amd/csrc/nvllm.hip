@@ -1168,6 +1168,13 @@ void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
     }
 }
 
+// after a forward's stream sync: did a P2P wait give up?  (a peer died or never called: the residual stream is garbage)
+void p2p_check(nvl_model* m) {
+    if (!m->p2p_ready) return;
+    int err = 0;
+    NVL_HIP(hipMemcpy(&err, m->p2p_buf + 960, 4, hipMemcpyDeviceToHost));
+    if (err) throw std::runtime_error("tensor-parallel all-reduce: timed out waiting for a peer rank (the group is unusable)");
+}
 // x += alpha * sum over the tensor-parallel ranks of `part` [M][N], by direct peer stores over the xGMI mesh (tp_p2p.h)
 void tp_p2p_allreduce_resid(nvl_model* m, const float* part, int M, int N, float alpha) {
     const int64_t count = (int64_t)M * N;
@@ -1178,7 +1185,7 @@ void tp_p2p_allreduce_resid(nvl_model* m, const float* part, int M, int N, float
     for (int r = 0; r < m->tp; r++) a.peer[r] = m->p2p_peer[r];
     a.off_ctr = 0; a.off_err = 960; a.off_in1 = m->p2p_off_in1; a.off_in2 = m->p2p_off_in2; a.off_res = m->p2p_off_res;
     a.in1_stride = m->p2p_in1_stride; a.in2_stride = m->p2p_in2_stride; a.res_stride = m->p2p_res_stride;
-    a.spin_limit = 4000000;                                   // x ~1 us of s_sleep: a few seconds, then fail instead of hanging
+    a.spin_limit = 3000000;                                   // x ~1 us of s_sleep: seconds, then the group is marked dead (off_err)
     const int nwg = (int)std::min<int64_t>(cdiv(count, 1024), 512);
     KScope ks(m, KC_OTHER, 0, KS_ALLREDUCE, (double)count * (m->f32 ? 4.0 : 2.0) * 2.0);
     const bool oneshot = M <= g_p2p_oneshot_rows && M <= P2P_ONESHOT_CAP_ROWS;
@@ -1748,6 +1755,7 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
         NVL_HIP(hipMemcpy2DAsync(logits_out, (size_t)m->V * 4, m->logits, (size_t)m->Vpad * 4, (size_t)m->V * 4,
                                  (size_t)rows, hipMemcpyDeviceToHost, m->stream));
     NVL_HIP(hipStreamSynchronize(m->stream));
+    p2p_check(m);
     m->last_rows = rows;
     if (argmax_out) {
         if (all) for (int i = 0; i < n_seqs; i++) argmax_out[i] = am_p[(size_t)h_last[i]];
@@ -1977,6 +1985,7 @@ void decode_loop(nvl_model* m, const Meta& hm, int n_seqs, int n_steps, int32_t*
     NVL_HIP(hipEventRecord(m->ev1, m->stream));
     NVL_HIP(hipMemcpyAsync(out_tokens, m->ring, (size_t)n_steps * n_seqs * 4, hipMemcpyDeviceToHost, m->stream));
     NVL_HIP(hipStreamSynchronize(m->stream));
+    p2p_check(m);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, m->ev0, m->ev1);
     m->stats.forward_calls += (uint64_t)n_steps;

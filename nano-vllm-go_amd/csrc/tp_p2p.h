@@ -56,10 +56,12 @@ __device__ __forceinline__ void p2p_signal_all(const P2PArgs& p, int kind) {
 __device__ __forceinline__ void p2p_wait(const P2PArgs& p, int kind) {
     if (threadIdx.x == 0) {
         const unsigned long long* c = p2p_ctr(p, p.rank, kind);
+        volatile int* err = (volatile int*)(p.peer[p.rank] + p.off_err);
         int it = 0;
-        while (__hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < p.target) {
+        // (once a wait has timed out the group is dead: later waits fall through at once, the host reports the error)
+        while (*err == 0 && __hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < p.target) {
             __builtin_amdgcn_s_sleep(32);
-            if (++it > p.spin_limit) { *(volatile int*)(p.peer[p.rank] + p.off_err) = 1; break; }      // give up, do not hang
+            if (++it > p.spin_limit) { *err = 1; break; }      // give up, do not hang
         }
     }
     __syncthreads();

@@ -110,6 +110,17 @@ class HipTransformerModel:
     def tp_init(self, unique_id: bytes):
         L.check(self.lib.nvl_tp_init(self.h, C.c_char_p(unique_id), len(unique_id)), self.h)
 
+    def tp_p2p_export(self) -> bytes:
+        """IPC handle (64 bytes) of this rank's all-reduce comm buffer (nvl_tp_p2p_export); gather them in rank order."""
+        buf = C.create_string_buffer(64)
+        L.check(self.lib.nvl_tp_p2p_export(self.h, buf, 64), self.h)
+        return buf.raw
+
+    def tp_p2p_attach(self, handles):
+        """handles: the tp_size exported handles in rank order (nvl_tp_p2p_attach): switches the all-reduce to direct peer stores."""
+        blob = b"".join(handles)
+        L.check(self.lib.nvl_tp_p2p_attach(self.h, C.c_char_p(blob), 64), self.h)
+
     @staticmethod
     def attach_local_group(models):
         arr = (C.c_void_p * len(models))(*[m.h.value for m in models])

@@ -163,3 +163,21 @@ def test_bench_launches_two_ranks_on_one_gpu(gpu):
     lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0
     assert lines[0]["config"]["parallelism"].startswith("dp2")
+
+
+def test_bench_tp_two_ranks_on_one_gpu(gpu):
+    """`python bench.py --gpus 2 --tp` started plainly: its own launcher starts the 2 ranks, they form ONE tensor-parallel
+    group whose all-reduces are the hand-written P2P exchange (both ranks on this box's one device), and rank 0 prints one
+    line with n_gpus = 2 and strong scaling.  The value is meaningless on one GPU; the control flow and the collective's
+    protocol are what is checked (tests/test_tp_p2p_gpu.py checks its arithmetic)."""
+    import json, os, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--tp", "--rehearse-on-one-gpu", "--batch", "2",
+                        "--prompt", "64", "--gen", "4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0 and lines[0]["scaling"] == "strong"
+    assert lines[0]["config"]["parallelism"].startswith("tp2") and "P2P" in lines[0]["config"]["parallelism"]
