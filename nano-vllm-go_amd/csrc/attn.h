@@ -74,6 +74,50 @@ __device__ __forceinline__ bf16x4 lds_read_tr4(const char* addr) {
     return __builtin_bit_cast(bf16x4, v);
 }
 
+// One LDS-DMA piece: 64 lanes x 16 bytes from sbase + voff (per lane) to LDS lds_addr + lane * 16.  Issued by inline
+// assembly ON PURPOSE: the compiler's wait-count pass knows the builtin form writes LDS and puts s_waitcnt vmcnt(0) in
+// front of the next transposed LDS read it sees — i.e. it waits for the tile that was issued a moment ago, two tiles ahead
+// of the one being read, and the ring degenerates to load-then-compute.  Through the assembly the pieces are invisible
+// to that pass; the kernel's own counted s_waitcnt vmcnt + barrier order them (vector loads return in order).
+// (s_nop 4: SGPR written by VALU -> read by VMEM needs 5 wait states, M0 write -> LDS-DMA needs 1; the hazard recogniser
+// does not look inside the assembly.  M0 is a reserved register and cannot be named as a clobber: the kernels that call
+// this use no other M0 consumer — no builtin LDS-DMA, no movrel, no GWS.)
+__device__ __forceinline__ void lds_dma16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+
+// single-instruction maxima: fmaxf on MFMA outputs makes the compiler canonicalise each input first (v_max x, x)
+// maximum of the 16 scores a lane holds, straight off the MFMA accumulators: two interleaved v_max3 chains in ONE asm
+// block.  The compiler inserts no hazard wait states for inline assembly (an MFMA result needs 8 before a VALU reads
+// it): the s_nop is that wait.
+__device__ __forceinline__ float vmax16(const f32x4& a, const f32x4& b, const f32x4& c, const f32x4& d) {
+    float r0, r1;
+    asm("s_nop 7\n\t"
+        "v_max3_f32 %0, %2, %3, %4\n\t"
+        "v_max3_f32 %1, %5, %6, %7\n\t"
+        "v_max3_f32 %0, %0, %8, %9\n\t"
+        "v_max3_f32 %1, %1, %10, %11\n\t"
+        "v_max3_f32 %0, %0, %12, %13\n\t"
+        "v_max3_f32 %1, %1, %14, %15\n\t"
+        "v_max3_f32 %0, %0, %16, %17\n\t"
+        "v_max_f32 %0, %0, %1"
+        : "=&v"(r0), "=&v"(r1)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+          "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]));
+    return r0;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+// maximum over the four 16-lane rows of the wave (lanes l, l^16, l^32, l^48) without going through LDS
+__device__ __forceinline__ float rows_max(float x) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float m = vmax2(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return vmax2(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 // ------------------------------------------------------------------------------------------
 // bf16 prefill kernel.  One workgroup = 8 waves = 256 query rows of one (sequence, kv head); each wave owns 32 rows as
 // two 16-row sub-tiles, so every K / V fragment read from LDS feeds two MFMAs.  K and V tiles (64 keys) stream
@@ -88,13 +132,15 @@ __global__ __launch_bounds__(512, HD == 64 ? 4 : 2) void attn_prefill_bf16_kerne
     constexpr int TILE_BYTES = 64 * HD * 2, PIECES = TILE_BYTES / 1024, PW = 2 * PIECES / 8, NBUF = 3;
     constexpr int QROWS = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // NBUF x [K image | V image]
+    __shared__ int32_t sblk[128];          // this sequence's block table (<= 128 blocks: host-checked)
 
-    // grid (kv head, query tile, sequence): consecutive block ids differ in the kv head, so with 8 | nKV every query tile of
+    // grid (kv head, sequence, query tile): consecutive block ids differ in the kv head, so with 8 | nKV every query tile of
     // one (sequence, kv head) lands on the same XCD (ids that differ by 8 share one) and re-reads its K/V tiles from that
-    // XCD's L2 instead of from HBM / the memory-side cache
-    // Query tiles are taken LAST FIRST: under the causal mask tile qt walks qt+1 key-tile groups, so the longest workgroups
-    // of a sequence are dispatched first and the short ones fill the tail.
-    const int seq = blockIdx.z, kvh = blockIdx.x, qt = gridDim.y - 1 - blockIdx.y;
+    // XCD's L2 instead of from HBM / the memory-side cache.
+    // Query tiles are the SLOWEST grid index and taken last first: under the causal mask tile qt walks qt+1 key-tile
+    // groups, so the whole batch is dispatched longest-workgroup-first and the short ones fill the tail.  (Sequence-major
+    // order left the last sequence's longest workgroups starting late: 61 % average occupancy at 8 x 2048.)
+    const int seq = blockIdx.y, kvh = blockIdx.x, qt = gridDim.z - 1 - blockIdx.z;
     const int S = p.seq_len[seq];
     const int R = S * p.group;                 // query rows of this (seq, kv head)
     if (qt * QROWS >= R) return;
@@ -103,6 +149,10 @@ __global__ __launch_bounds__(512, HD == 64 ? 4 : 2) void attn_prefill_bf16_kerne
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fq = lane & 15, fg = lane >> 4;
+    // The block ids go through LDS: inside the tile loop the ONLY vector-memory operations may be the LDS-DMA pieces —
+    // a register-returning load there (or a load still pending at loop entry) makes the compiler wait with vmcnt(0), which
+    // also waits for the DMA issued a moment ago and serialises the whole ring (measured: 4200 cycles per tile instead of ~1300)
+    if (tid < p.tbl_stride && tid < 128) sblk[tid] = tbl[tid];
 
     // ---- this lane's query rows (one per sub-tile); position and head are re-derived where needed (registers) ----
     bf16x8 qf[TQ][KS];
@@ -119,6 +169,13 @@ __global__ __launch_bounds__(512, HD == 64 ? 4 : 2) void attn_prefill_bf16_kerne
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) qf[qi][ks] = *(const bf16x8*)(qp + ks * 32 + fg * 8);
     }
+    // the Q fragments are complete before the first DMA is issued (an empty asm that "rewrites" them: the compiler waits
+    // here, once, and no register is pending on a vector load when the loop starts)
+#pragma unroll
+    for (int qi = 0; qi < TQ; qi++)
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) asm volatile("" : "+v"(qf[qi][ks]));
+    __syncthreads();                      // sblk is visible
     int last_row = qt * QROWS + QROWS - 1;
     if (last_row > R - 1) last_row = R - 1;
     const int n_kt = (pos0 + last_row / p.group) / 64 + 1;
@@ -136,18 +193,19 @@ __global__ __launch_bounds__(512, HD == 64 ? 4 : 2) void attn_prefill_bf16_kerne
         const int jj = (wave * PW + i) % PIECES;
         const int pos16 = jj * 64 + lane, row = pos16 / CPR, pc = pos16 % CPR;
         const int c = (((pc >> 1) ^ kv_swz<HD>(row)) << 1) | (pc & 1);
-        src_off[i] = row * HD + c * 8;
+        src_off[i] = (row * HD + c * 8) * 2;            // bytes
     }
+    const uint32_t smem_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
     auto issue = [&](int kt, int buf) {
         const int bi = kv_block_index(p, kt * 64), krow0 = kt * 64 - bi * p.Tmax;      // (64 | Tmax: no straddling)
-        const int64_t blk_off = (int64_t)tbl[bi] * p.slot_stride + ((int64_t)kvh * p.Tmax + krow0) * HD;
-        char* dst = smem + buf * (2 * TILE_BYTES) + wave * (PW * 1024);               // (K pieces first, then V pieces)
+        const int blk = __builtin_amdgcn_readfirstlane(sblk[bi]);
+        const int64_t blk_off = (int64_t)blk * p.slot_stride + ((int64_t)kvh * p.Tmax + krow0) * HD;
+        const uint32_t dst = smem_lds + buf * (2 * TILE_BYTES) + wave * (PW * 1024);  // (K pieces first, then V pieces)
 #pragma unroll
         for (int i = 0; i < PW; i++) {
             const bool is_v = (wave * PW + i) >= PIECES;
             const bf16_t* base = (const bf16_t*)(is_v ? p.vcache : p.kcache) + blk_off;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + src_off[i]),
-                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+            lds_dma16(base, (uint32_t)src_off[i], dst + i * 1024);
         }
     };
 
@@ -161,10 +219,12 @@ __global__ __launch_bounds__(512, HD == 64 ? 4 : 2) void attn_prefill_bf16_kerne
     for (int d = 0; d < DT; d++) v_off[d] = 16 * kv_img_chunk<HD>(4 * fg + q4, 2 * d + (p4 >> 1)) + 8 * (p4 & 1);
 
     f32x4 o[TQ][DT];
-    float m_run[TQ], l_run[TQ];
+    f32x4 lacc[TQ];                   // softmax denominators out of the MFMA pipe: ones · P^T, every row the complete sum
+    float m_run[TQ];
 #pragma unroll
     for (int qi = 0; qi < TQ; qi++) {
-        m_run[qi] = -INFINITY; l_run[qi] = 0.f;
+        m_run[qi] = -INFINITY;
+        lacc[qi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int d = 0; d < DT; d++) o[qi][d] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -205,48 +265,44 @@ __global__ __launch_bounds__(512, HD == 64 ? 4 : 2) void attn_prefill_bf16_kerne
             }
         // lane holds S^T[key = kt*64 + 16t + 4fg + r][q = fq] per sub-tile
         const bool whole = kt * 64 + 63 <= wave_first_limit;      // every row of the wave sees the whole tile
+        if (!whole) {                                             // a tile on the causal diagonal
 #pragma unroll
-        for (int qi = 0; qi < TQ; qi++) {
-            // scores stay RAW; the softmax scale (sl2 > 0: checked by the host) is folded into the exponent's fma:
-            // p = exp2(s * sl2 - m), m = running max of s * sl2
-            float tmax = -INFINITY;
-            if (whole) {
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-                    tmax = fmaxf(tmax, fmaxf(fmaxf(s[qi][t][0], s[qi][t][1]), fmaxf(s[qi][t][2], s[qi][t][3])));
-            } else {
+            for (int qi = 0; qi < TQ; qi++) {
                 bool ok;
                 const int lim = pos0 + row_of(qi, ok) / p.group - kt * 64 - fg * 4;   // last key (tile-relative) this row may see
 #pragma unroll
                 for (int t = 0; t < 4; t++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float v = (t * 16 + r <= lim) ? s[qi][t][r] : -INFINITY;     // reference: -1e10 then exp() == 0 exactly
-                        s[qi][t][r] = v;
-                        tmax = fmaxf(tmax, v);
-                    }
+                    for (int r = 0; r < 4; r++)
+                        s[qi][t][r] = (t * 16 + r <= lim) ? s[qi][t][r] : -INFINITY;  // reference: -1e10 then exp() == 0 exactly
             }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run[qi], tmax * sl2);   // finite from the first tile on: key 0 <= limit
-            float psum = 0.f;
+        }
+        // scores stay RAW; the softmax scale (sl2 > 0: checked by the host) is folded into the exponent's fma:
+        // p = exp2(s * sl2 - m), m = running max of s * sl2 (finite from the first tile on: key 0 <= limit)
+        float m_new[TQ];
+        bool moved = false;
+#pragma unroll
+        for (int qi = 0; qi < TQ; qi++) {
+            const float tmax = rows_max(vmax16(s[qi][0], s[qi][1], s[qi][2], s[qi][3]));
+            m_new[qi] = vmax2(m_run[qi], tmax * sl2);
+            moved |= m_new[qi] != m_run[qi];
+        }
+        if (__any(moved)) {                                       // the running maximum moved for some row: rescale
+#pragma unroll
+            for (int qi = 0; qi < TQ; qi++) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new[qi]);
+                lacc[qi] *= alpha;
+#pragma unroll
+                for (int d = 0; d < DT; d++) o[qi][d] *= alpha;
+                m_run[qi] = m_new[qi];
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < TQ; qi++)
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[qi][t][r], sl2, -m_new));
-                    s[qi][t][r] = pv;
-                    psum += pv;
-                }
-            if (__any(m_new != m_run[qi])) {                 // the running maximum moved for some row: rescale
-                const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
-                l_run[qi] *= alpha;
-#pragma unroll
-                for (int d = 0; d < DT; d++) o[qi][d] *= alpha;
-            }
-            l_run[qi] += psum;
-            m_run[qi] = m_new;
-        }
+                for (int r = 0; r < 4; r++) s[qi][t][r] = __builtin_amdgcn_exp2f(fmaf(s[qi][t][r], sl2, -m_new[qi]));
 
         // ---- O^T += V^T · P^T : the V^T operand comes out of the row-major V image by transposed LDS reads; the k index
         // (keys 32u + 4fg + r, then 32u + 16 + 4fg + r) is permuted identically on both operands ----
@@ -271,14 +327,20 @@ __global__ __launch_bounds__(512, HD == 64 ? 4 : 2) void attn_prefill_bf16_kerne
                 for (int qi = 0; qi < TQ; qi++)
                     o[qi][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qi], o[qi][d], 0, 0, 0);
             }
+            // the row sums of P (as rounded for the product above) ride the MFMA pipe too: 32 f32 adds less per tile on
+            // the vector ALU, which is the busier unit here
+            bf16x8 ones;
+#pragma unroll
+            for (int r = 0; r < 8; r++) ones[r] = (bf16_t)1.0f;
+#pragma unroll
+            for (int qi = 0; qi < TQ; qi++)
+                lacc[qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qi], lacc[qi], 0, 0, 0);
         }
     }
 
 #pragma unroll
     for (int qi = 0; qi < TQ; qi++) {
-        float l = l_run[qi];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        const float l = lacc[qi][0];
         bool ok;
         const int row = row_of(qi, ok), si = row / p.group, hd_ = kvh * p.group + (row - si * p.group);
         if (!ok) continue;

@@ -1082,7 +1082,8 @@ void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, do
     } else {
         // 256 query rows (position x head-in-group, position-major) per workgroup of 8 waves; K/V tiles by LDS-DMA
         const int64_t qrows = (int64_t)max_len * m->group;
-        dim3 grid(m->nKV, cdiv(qrows, 256), n_seqs);      // (kv head fastest: attn.h)
+        if (m->blocks_per_seq > 128) throw std::runtime_error("attention: more than 128 KV blocks per sequence");
+        dim3 grid(m->nKV, n_seqs, cdiv(qrows, 256));      // (kv head fastest, query tile slowest: attn.h)
         if (m->hd == 64) {
             hipLaunchKernelGGL((attn_prefill_bf16_kernel<64>), grid, dim3(512), attn_prefill_lds_bytes<64>(), m->stream, a);
         } else {
