@@ -107,10 +107,12 @@ def label_passes(rows, name_key="Kernel_Name"):
                         site = "lm_head"
                     elif "attn_" in nxt or "rope_kv" in nxt:
                         site = "qkv_proj"
+                    elif last == "moe_up":          # the grouped expert-down GEMM (moe_combine follows it)
+                        site = "moe_down"
                     elif "moe_" in nxt:
                         site = "moe_router"
                     else:
-                        site = "moe_down" if last in ("moe_up",) else "other_gemm"
+                        site = "other_gemm"
                 if site == "ffn_up" and any("moe_" in q["kname"] for q in p):
                     site = "moe_up"
             elif "norm" in n:
@@ -124,6 +126,6 @@ def label_passes(rows, name_key="Kernel_Name"):
             elif "rope_kv" in n:
                 site = "rope_kv"
             r["site"], r["phase"] = site, phase
-            if site in ("attention", "ffn_up", "moe_up", "o_proj", "ffn_down", "qkv_proj"):
+            if site in ("attention", "ffn_up", "moe_up", "moe_down", "o_proj", "ffn_down", "qkv_proj"):
                 last = site
     return passes
