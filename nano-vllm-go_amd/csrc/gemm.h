@@ -436,7 +436,23 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = (p.N + BN - 1) / BN;
     int tm, tn;
-    tile_coords(xcd_remap(blockIdx.x, gridDim.x), gridDim.x / tiles_n, tiles_n, 4, tm, tn);
+    int row_base = 0;
+    if (p.tile_map) {
+        // grouped launch (MoE prefill): m-tile ti = (expert, 256-row segment of its rows in the expert-ordered buffer).
+        // After xcd_remap an XCD owns a contiguous range of (ti, tn): whole experts, so an expert's weights and each
+        // row segment are re-read from that XCD's L2 by the tiles that share them.
+        const int pid = xcd_remap(blockIdx.x, gridDim.x);
+        tn = pid % tiles_n;
+        const int ti = pid / tiles_n;
+        if (ti >= *p.n_mtiles) return;                    // (whole workgroup: before any barrier)
+        row_base = p.tile_map[4 * ti + 1];
+        p.M = p.tile_map[4 * ti + 2];
+        p.c_row0 = row_base;
+        p.W = (const bf16_t*)p.W + (int64_t)p.tile_map[4 * ti] * p.w_expert_stride;
+        tm = 0;
+    } else {
+        tile_coords(xcd_remap(blockIdx.x, gridDim.x), gridDim.x / tiles_n, tiles_n, 4, tm, tn);
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int grp = wave >> 2;                            // the ping-pong group: first / second dispatched half
@@ -450,6 +466,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmArgs p) {
         if (blk < NA) {
             int am = m0 + blk * 16 + fr;
             if (am > p.M - 1) am = p.M - 1;
+            am += row_base;                               // (a segment may start on any row: per-lane 16-byte sources)
             src[i] = (const bf16_t*)p.A + (((int64_t)(am >> 4) * (p.K >> 5) * 64) + (am & 15) + 16 * fg) * 8;
         } else {
             src[i] = (const bf16_t*)p.W + ((int64_t)((n0 >> 4) + blk - NA) * (p.K >> 5) * 64 + lane) * 8;
@@ -1046,6 +1063,11 @@ static inline double cu_fill(int tiles, int per_cu) {
 
 template <int EPI, typename OutT>
 static inline void launch_gemm_grouped(hipStream_t st, const GemmArgs& a, int max_mtiles) {
+    if (a.grp_bm == 512) {      // prefill MoE, the default: 256-row m-tiles on the ping-pong kernel
+        NVL_LDS_ATTR((gemm_bf16_pp_kernel<EPI, OutT, 4, 0>), 4 * 32 * 1024);
+        hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, OutT, 4, 0>), dim3(cdiv(a.N, 256) * max_mtiles), dim3(512), 4 * 32 * 1024, st, a);
+        return;
+    }
     if (a.grp_bm == 256) {      // prefill MoE with long expert segments: 256-row m-tiles, three stages
         constexpr int lds3 = gemm_lds_bytes<256, 128, 3>();
         NVL_LDS_ATTR((gemm_bf16_kernel<256, 128, 4, 2, 3, EPI, OutT>), lds3);

@@ -1218,7 +1218,7 @@ void tp_p2p_allreduce_resid(nvl_model* m, const float* part, int M, int N, float
 static int g_qkv_store_max_m = 256;   // nvl_set_tuning key 18: largest prefill batch whose QKV projection runs as decode-form groups + rope_kv_kernel
 static int g_moe_dense = 1;    // nvl_set_tuning key 22: decode MoE as two dense-masked projections (gemm.h moe_gate); 0 = sort + grouped GEMMs
 static int g_moe_deep = 1;     // nvl_set_tuning key 19: four-stage grouped GEMM for decode-sized MoE batches (0 = two stages)
-static int g_moe_bm = 0;       // nvl_set_tuning key 17: m-tile rows of the grouped MoE GEMMs (0 / 128: 128, 256)
+static int g_moe_bm = 0;       // nvl_set_tuning key 17: prefill MoE grouped GEMMs: 0 = 256-row tiles on the ping-pong kernel, 128 / 256 = the lock-step tile kernels
 static int g_moe_gather = 1;   // nvl_set_tuning key 16: prefill MoE gathers the token rows into expert order before the grouped GEMM (0 = per-lane gather inside it)
 static int g_moe_small = 1;    // nvl_set_tuning key 8: fused MoE planning launch + combine folded into the next norm (0 = off)
 static int g_decode_seam = 1;  // nvl_set_tuning key 7: decode_seam_kernel in nvl_decode_greedy (0 = separate kernels)
@@ -1344,7 +1344,9 @@ void moe(nvl_model* m, const LayerW& l, int M, bool deferred_norm = false) {
     const bool small = !m->f32 && M <= 64 && pairs <= MOE_PLAN_MAX_PAIRS && E <= MOE_PLAN_MAX_E && g_moe_small;
     // m-tile height of the grouped GEMMs: 128 rows; the 256x128 three-stage instance stays a tuning option (Granite-1B,
     // 4096 rows per expert: 441 K vs 450 K prefill tok/s)
-    const int BM = (!m->f32 && !small && g_moe_bm == 256) ? 256 : 128;
+    // prefill default: 256-row m-tiles on the ping-pong kernel (needs the rows copied into expert order and K >= 160)
+    const bool pp = !m->f32 && !small && g_moe_bm == 0 && m->moe_xg && g_moe_gather && H >= 160 && I >= 160 && (2 * I) % 256 == 0 && H % 256 == 0;
+    const int BM = pp ? 256 : ((!m->f32 && !small && g_moe_bm == 256) ? 256 : 128);
     if (small) {
         KScope ks(m, KC_OTHER, 0, KS_MOE_PLAN);
         hipLaunchKernelGGL(moe_plan_kernel, dim3(1), dim3(M <= 4 ? 256 : (M <= 8 ? 512 : 1024)), 0, m->stream, m->router_logits, 128, M, E, k, 128, m->expert_ids,
@@ -1396,11 +1398,11 @@ void moe(nvl_model* m, const LayerW& l, int M, bool deferred_norm = false) {
             NVL_HIP(hipGetLastError());
             a.A = m->moe_xg; a.a_rows = nullptr;
         }
-        a.w_expert_stride = (int64_t)2 * I * H; a.grp_bm = BM; a.grp_deep = small && g_moe_deep;
+        a.w_expert_stride = (int64_t)2 * I * H; a.grp_bm = pp ? 512 : BM; a.grp_deep = small && g_moe_deep;
         m->site = KS_MOE_UP; m->site_bytes = (e_touch * 2 * I * H + (double)pairs * H + (double)pairs * I) * (double)m->wsize;
         gemm(m, EPI_SWIGLU, false, a, 2.0 * pairs * 2 * I * H);
         GemmArgs d = mk(m->hbuf, I, l.t[NVL_T_MOE_OUT].p, m->moe_eo, H, nullptr, 1.f, max_mtiles, H, I);
-        d.tile_map = m->moe_tile_map; d.n_mtiles = m->moe_n_mtiles; d.w_expert_stride = (int64_t)H * I; d.grp_bm = BM; d.grp_deep = small && g_moe_deep;
+        d.tile_map = m->moe_tile_map; d.n_mtiles = m->moe_n_mtiles; d.w_expert_stride = (int64_t)H * I; d.grp_bm = pp ? 512 : BM; d.grp_deep = small && g_moe_deep;
         m->site = KS_MOE_DOWN; m->site_bytes = (e_touch * H * I + (double)pairs * I) * (double)m->wsize + (double)pairs * H * 4.0;
         gemm(m, EPI_STORE, true, d, 2.0 * pairs * H * I);
     }

@@ -265,6 +265,30 @@ def test_moe(gpu, oracle, precision, rows, E, k):
     assert rel_err(got[clear], want[clear]) <= 3e-2
 
 
+def test_moe_prefill_pingpong_tiles(gpu, oracle):
+    """Prefill MoE on shapes the grouped ping-pong GEMM takes (H % 256 == 0, 2I % 256 == 0, rows in expert order):
+    256-row m-tiles that start on arbitrary rows of the expert-ordered buffer and end ragged.  Same k order as the
+    lock-step 128-row tiles, so the two are bit-identical; against the oracle on the rows with a clear top-k."""
+    r = rng(77)
+    rows, E, k, H, I = 900, 8, 2, 256, 256
+    x = r.standard_normal((rows, H), dtype=np.float32)
+    router = r.standard_normal((H, E), dtype=np.float32) * 0.3
+    w_in = r.standard_normal((E, 2 * I, H), dtype=np.float32) * 0.1
+    w_out = r.standard_normal((E, H, I), dtype=np.float32) * 0.1
+    got = gpu.ops.moe_forward(x, router, w_in, w_out, k, precision="bf16")
+    old = gpu.lib().nvl_set_tuning(17, 128)
+    try:
+        alt = gpu.ops.moe_forward(x, router, w_in, w_out, k, precision="bf16")
+    finally:
+        gpu.lib().nvl_set_tuning(17, old)
+    assert np.array_equal(alt, got)
+    want = oracle.moe(x, router, w_in, w_out, k)
+    logits = np.sort(x.astype(np.float64) @ router.astype(np.float64), axis=1)[:, ::-1]
+    clear = (logits[:, k - 1] - logits[:, k]) > 0.1
+    assert clear.mean() > 0.5
+    assert rel_err(got[clear], want[clear]) <= 3e-2
+
+
 def test_argmax_first_max_tie_rule(gpu, oracle):
     x = np.zeros((3, 50257), np.float32)
     x[0, [5, 40000]] = 2.0          # tie -> lowest index (cmd/ask/main.go:396 strict >)
