@@ -662,6 +662,14 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u], x[u][i], acc[i], 0, 0, 0);
     };
     if (nblk > 0) load_blk(wA, xA, 0);
+    // the residual operand of this wave's first epilogue element (deferred-norm producer form): fetched under the weight
+    // stream, not as a dependent round trip after the K reduction (this launch is the only writer of these elements)
+    f32x4 x_pre = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_RESID && !MOE && p.rs_out && wave < NTW * MT) {
+        const int t = wave / MT, i = wave - t * MT;
+        const int m = 16 * (i + i_off) + fr, n = (nt0 + t) * 16 + 4 * fg;
+        if (m < p.M && n < p.N) x_pre = *(const f32x4*)((const float*)p.C + (int64_t)m * p.ldc + n);
+    }
     int b = 0;
     for (; b + 2 <= nblk; b += 2) {
         load_blk(wB, xB, b + 1);
@@ -713,7 +721,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
             if (m < p.M && n < p.N) {
                 if (p.bias) v += *(const f32x4*)(p.bias + n);
                 float* x = (float*)p.C + (int64_t)m * p.ldc + n;
-                const f32x4 o = *(f32x4*)x + p.alpha * v;
+                const f32x4 o = (e == wave ? x_pre : *(f32x4*)x) + p.alpha * v;
                 *(f32x4*)x = o;
                 act_store4<bf16_t>(p.nrm_xn, m, n, p.N, o * *(const f32x4*)(p.nrm_w + n));
                 ss = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
