@@ -399,10 +399,15 @@ int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int 
  * decode GEMM form, in one launch interleaved over the weight blocks (key 13 = 1) or one launch per group (0); up to
  * key 14 rows (64) every projection does.  key 15: waves per decode-attention workgroup (0 = from context length and
  * grid size, 2, 4, 8).  key 16: prefill MoE copies the token rows into expert order before the grouped GEMM (1, default)
- * or gathers them per lane inside it (0).  key 17: rows per m-tile of the grouped MoE GEMMs (128 default, 256).
+ * or gathers them per lane inside it (0).  key 17: prefill MoE grouped GEMMs: 0 (default) = 256-row segments on the
+ * ping-pong kernel, 128 / 256 = the lock-step tile kernels with that many rows per m-tile.
  * key 19: decode-sized MoE batches run the grouped GEMMs on the four-stage 128x128 instance (1, default) or two stages (0).
  * key 18: largest prefill batch (tokens) whose QKV projection runs as decode-form groups + rope_kv_kernel instead of the
  * fused-epilogue tile kernel (default 256: +5 % at 128 tokens, +1 % at 256, -4 % at 512).
+ * key 21: hipGraph replay of decode passes (1, default; 0 = every launch eager).  key 22: decode MoE as two dense-masked
+ * weight-streaming projections (1, default) or sort + grouped GEMMs (0).  key 23: largest payload (rows of the residual
+ * stream) the tensor-parallel P2P all-reduce sends one-shot; above it reduce-scatter + all-gather (default 64).
+ * Every call starts a new tuning epoch: captured decode graphs bake the tuning in and are re-captured.
  * Returns the previous value. */
 int nvl_set_tuning(int key, int value);
 

@@ -152,6 +152,18 @@ func NewHipModelRunner(modelDir string, o Options) (*HipModelRunner, error) {
 	cfg.attention_multiplier = C.float(c.AttentionMultiplier)
 	cfg.residual_multiplier = C.float(c.ResidualMultiplier)
 	cfg.logits_scaling = C.float(c.LogitsScaling)
+	// Granite-4 hybrid (config.go:100-115): which layers are Mamba2 blocks, and their geometry
+	for li, kind := range c.HybridLayers {
+		if (kind == "mamba" || kind == "mamba2") && li < 128 {
+			cfg.mamba_layer_mask[li/64] |= C.uint64_t(1) << uint(li%64)
+			cfg.mamba_expand = C.int32_t(c.Mamba2Expand)
+			cfg.mamba_state_size = C.int32_t(c.Mamba2StateSize)
+			cfg.mamba_num_heads = C.int32_t(c.Mamba2NumHeads)
+			cfg.mamba_head_dim = C.int32_t(c.Mamba2HeadDim)
+			cfg.mamba_n_groups = C.int32_t(c.Mamba2NGroups)
+			cfg.mamba_conv_kernel = C.int32_t(c.Mamba2ConvKernel)
+		}
+	}
 
 	r, err := create(&cfg, o)
 	if err != nil {
@@ -174,8 +186,12 @@ func NewHipModelRunner(modelDir string, o Options) (*HipModelRunner, error) {
 		}
 		// the library copies out of the buffer before returning (synchronous upload): a Go pointer for
 		// the duration of the call is within the cgo rules
+		layout := C.int(C.NVL_LAYOUT_IN_OUT)
+		if kind == C.NVL_T_MAMBA_IN_PROJ || kind == C.NVL_T_MAMBA_OUT_PROJ {
+			layout = C.NVL_LAYOUT_OUT_IN // loadMamba2 keeps the PyTorch layout (generic_loader.go:461-512)
+		}
 		rc := C.nvl_upload_tensor(r.h, kind, C.int(layer), unsafe.Pointer(&t.Data[0]), C.NVL_DTYPE_F32,
-			C.int64_t(rows), C.int64_t(cols), C.NVL_LAYOUT_IN_OUT)
+			C.int64_t(rows), C.int64_t(cols), layout)
 		runtime.KeepAlive(t)
 		if rc != 0 {
 			return r.err()
@@ -228,6 +244,15 @@ func NewHipModelRunner(modelDir string, o Options) (*HipModelRunner, error) {
 			add(C.NVL_T_WQ, i, a.QWeight)
 			add(C.NVL_T_WKV, i, a.KVWeight)
 			add(C.NVL_T_WO, i, a.OutWeight)
+		case *tensor.Mamba2Layer: // mamba2.go:9-27; the state lives per sequence on the device (DESIGN.md §9 f-4)
+			add(C.NVL_T_MAMBA_IN_PROJ, i, a.InProj)
+			add(C.NVL_T_MAMBA_CONV_W, i, a.ConvWeight)
+			add(C.NVL_T_MAMBA_CONV_B, i, a.ConvBias)
+			add(C.NVL_T_MAMBA_A_LOG, i, a.ALog)
+			add(C.NVL_T_MAMBA_D, i, a.D)
+			add(C.NVL_T_MAMBA_DT_BIAS, i, a.DeltaBias)
+			add(C.NVL_T_MAMBA_NORM, i, a.Norm)
+			add(C.NVL_T_MAMBA_OUT_PROJ, i, a.OutProj)
 		default:
 			return fail(fmt.Errorf("nvllm: layer %d: attention layer type %T is not on the device path", i, b.Attention))
 		}
