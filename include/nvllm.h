@@ -407,6 +407,7 @@ int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int 
  * key 21: hipGraph replay of decode passes (1, default; 0 = every launch eager).  key 22: decode MoE as two dense-masked
  * weight-streaming projections (1, default) or sort + grouped GEMMs (0).  key 23: largest payload (rows of the residual
  * stream) the tensor-parallel P2P all-reduce sends one-shot; above it reduce-scatter + all-gather (default 64).
+ * key 24: the decode GEMM kernels do not fetch the activation rows >= M of a padded 16-row tile (1, default).
  * Every call starts a new tuning epoch: captured decode graphs bake the tuning in and are re-captured.
  * Returns the previous value. */
 int nvl_set_tuning(int key, int value);

@@ -71,6 +71,7 @@ struct GemmArgs {
     const int32_t* tile_map;
     const int32_t* n_mtiles;
     int64_t w_expert_stride;
+    int x_mask;             // decode kernels: rows >= M of a 16-row activation tile are not fetched (set when M % 16 != 0)
     int grp_bm;             // rows per m-tile of the grouped launch (128, or 256: the 256x128 three-stage instance)
     int grp_deep;           // grouped launch on the four-stage 128x128 instance (decode-sized MoE batches)
     QkvEpi qkv;             // EPI_QKV
@@ -641,6 +642,13 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     f32x4 acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Only the lanes of rows < M fetch their activation fragment (the rest feed zeros: their output columns are never
+    // stored).  The CU's ingest rate, not HBM, bounds these kernels, and at M = 1 a padded 16-row fragment would be as
+    // many bytes as the weight fragment beside it (M <= 4: a quarter of it with the mask, four 64-byte sectors).
+    bool x_live[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) x_live[i] = !p.x_mask || 16 * (i + i_off) + fr < p.M;   // (x_mask: the host sets it when M % 16 != 0)
+    const bf16x8 x_zero = {};
 
     // k loop: blocks of U k-steps (U*32 of K), two register sets -> the next block's loads are in
     // flight while the current block's MFMAs issue (the compiler emits counted vmcnt for these).
@@ -651,7 +659,10 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
         for (int u = 0; u < U; u++) {
             w[u] = weight_load<PASSES>((const bf16x8*)(wp + (int64_t)(b * U + u) * 512));
 #pragma unroll
-            for (int i = 0; i < MT; i++) x[u][i] = *(const bf16x8*)(xp[i] + (int64_t)(b * U + u) * 512);
+            for (int i = 0; i < MT; i++) {
+                const bf16x8* src = (const bf16x8*)(xp[i] + (int64_t)(b * U + u) * 512);
+                if (p.x_mask) x[u][i] = x_live[i] ? *src : x_zero; else x[u][i] = *src;      // (uniform branch)
+            }
         }
     };
     auto comp_blk = [&](bf16x8 (&w)[U], bf16x8 (&x)[U][MT]) {
@@ -682,7 +693,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
         const bf16x8 w = weight_load<PASSES>((const bf16x8*)(wp + (int64_t)s * 512));
 #pragma unroll
         for (int i = 0; i < MT; i++)
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, *(const bf16x8*)(xp[i] + (int64_t)s * 512), acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x_live[i] ? *(const bf16x8*)(xp[i] + (int64_t)s * 512) : x_zero, acc[i], 0, 0, 0);
     }
 
     // ---- reduce the K slices in wave order ----
@@ -846,6 +857,10 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
 #pragma unroll
         for (int i = 0; i < MT; i++) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    bool x_live[MT];                                 // (see the narrow kernel: rows >= M are not fetched)
+#pragma unroll
+    for (int i = 0; i < MT; i++) x_live[i] = !p.x_mask || 16 * i + fr < p.M;
+    const bf16x8 x_zero = {};
     const int nblk = my_steps / U;
     bf16x8 wA[U][NTB], xA[U][MT], wB[U][NTB], xB[U][MT];
     auto load_blk = [&](bf16x8 (&w)[U][NTB], bf16x8 (&x)[U][MT], int b) {
@@ -855,7 +870,10 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
             for (int t = 0; t < NTB; t++)
                 w[u][t] = weight_load<PASSES>((const bf16x8*)(wp + t * tile_stride + (int64_t)(b * U + u) * 512));
 #pragma unroll
-            for (int i = 0; i < MT; i++) x[u][i] = *(const bf16x8*)(xp + i * tile_stride + (int64_t)(b * U + u) * 512);
+            for (int i = 0; i < MT; i++) {
+                const bf16x8* src = (const bf16x8*)(xp + i * tile_stride + (int64_t)(b * U + u) * 512);
+                if (p.x_mask) x[u][i] = x_live[i] ? *src : x_zero; else x[u][i] = *src;      // (uniform branch)
+            }
         }
     };
     auto comp_blk = [&](bf16x8 (&w)[U][NTB], bf16x8 (&x)[U][MT]) {
@@ -879,7 +897,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
     for (int s = nblk * U; s < my_steps; s++) {      // ragged tail
         bf16x8 xs[MT];
 #pragma unroll
-        for (int i = 0; i < MT; i++) xs[i] = *(const bf16x8*)(xp + i * tile_stride + (int64_t)s * 512);
+        for (int i = 0; i < MT; i++) xs[i] = x_live[i] ? *(const bf16x8*)(xp + i * tile_stride + (int64_t)s * 512) : x_zero;
 #pragma unroll
         for (int t = 0; t < NTB; t++) {
             const bf16x8 w = weight_load<PASSES>((const bf16x8*)(wp + t * tile_stride + (int64_t)s * 512));
@@ -925,6 +943,7 @@ static int g_msplit_ks = 8;         // K split of the deferred-norm residual pro
 static int g_narrow_waves = 1024;   // waves per narrow-form launch (nvl_set_tuning key 5); in the model (weights cold from HBM) fewer,
                                     // longer per-wave streams win: B=8 +8 %, B=16 +8 %, B=32 +3 % decode vs 4096
 static int g_wide_ksplit = 0;   // experiment (nvl_set_tuning key 4): K split of the wide form when groups <= 512
+static int g_x_mask = 1;            // nvl_set_tuning key 24: decode kernels skip the activation fetch of padded rows (M % 16 != 0)
 static int g_force_ntw = 0, g_force_ksplit = 0;   // tuning overrides (nvl_bench_gemm only)
 static int g_force_tile = 0;                      // 0 automatic, 1: 128x128x2st, 2: 256x128x3st, 3: 256x256x2st, 5: ping-pong 256x256
 
@@ -1040,9 +1059,11 @@ static inline bool launch_gemm_skinny_wide(hipStream_t st, const GemmArgs& a) {
     return true;
 }
 template <int EPI, typename OutT>
-static inline bool launch_gemm_skinny_bf16(hipStream_t st, const GemmArgs& a) {
+static inline bool launch_gemm_skinny_bf16(hipStream_t st, const GemmArgs& a0) {
     if (EPI == EPI_QKV) return false;               // prefill-only epilogue (a decode workgroup owns 16 columns, not a head)
-    if (skinny_rows(a) > 64 || a.a_rows || a.seg || a.tile_map) return false;
+    if (skinny_rows(a0) > 64 || a0.a_rows || a0.seg || a0.tile_map) return false;
+    GemmArgs a = a0;
+    a.x_mask = (g_x_mask && a0.M % 16 != 0) ? 1 : 0;     // padded rows of the last 16-row activation tile are not fetched
     if constexpr (EPI == EPI_SWIGLU || EPI == EPI_STORE || EPI == EPI_GELU) {
         // wide-N form once its 64-row groups fill the chip (g_force_ntw: 8 forces it, 1/2/4 force the narrow form)
         const bool wide_ok = skinny_rows(a) > 16 && cdiv(a.N, 64) >= 256 && !a.sk_part;   // M <= 16: the narrow form streams as fast
