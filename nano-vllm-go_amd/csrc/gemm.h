@@ -857,10 +857,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
 #pragma unroll
         for (int i = 0; i < MT; i++) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    bool x_live[MT];                                 // (see the narrow kernel: rows >= M are not fetched)
-#pragma unroll
-    for (int i = 0; i < MT; i++) x_live[i] = !p.x_mask || 16 * i + fr < p.M;
-    const bf16x8 x_zero = {};
+    // (no row mask here, unlike the narrow kernel: this form runs at 17..64 rows, where at most one tile is ragged, and its
+    // 256-register budget is full — the predicated loads cost 6 more spilled registers and 2 us per FFN-up launch at B = 32)
     const int nblk = my_steps / U;
     bf16x8 wA[U][NTB], xA[U][MT], wB[U][NTB], xB[U][MT];
     auto load_blk = [&](bf16x8 (&w)[U][NTB], bf16x8 (&x)[U][MT], int b) {
@@ -870,10 +868,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
             for (int t = 0; t < NTB; t++)
                 w[u][t] = weight_load<PASSES>((const bf16x8*)(wp + t * tile_stride + (int64_t)(b * U + u) * 512));
 #pragma unroll
-            for (int i = 0; i < MT; i++) {
-                const bf16x8* src = (const bf16x8*)(xp + i * tile_stride + (int64_t)(b * U + u) * 512);
-                if (p.x_mask) x[u][i] = x_live[i] ? *src : x_zero; else x[u][i] = *src;      // (uniform branch)
-            }
+            for (int i = 0; i < MT; i++) x[u][i] = *(const bf16x8*)(xp + i * tile_stride + (int64_t)(b * U + u) * 512);
         }
     };
     auto comp_blk = [&](bf16x8 (&w)[U][NTB], bf16x8 (&x)[U][MT]) {
@@ -897,7 +892,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
     for (int s = nblk * U; s < my_steps; s++) {      // ragged tail
         bf16x8 xs[MT];
 #pragma unroll
-        for (int i = 0; i < MT; i++) xs[i] = x_live[i] ? *(const bf16x8*)(xp + i * tile_stride + (int64_t)s * 512) : x_zero;
+        for (int i = 0; i < MT; i++) xs[i] = *(const bf16x8*)(xp + i * tile_stride + (int64_t)s * 512);
 #pragma unroll
         for (int t = 0; t < NTB; t++) {
             const bf16x8 w = weight_load<PASSES>((const bf16x8*)(wp + t * tile_stride + (int64_t)s * 512));
