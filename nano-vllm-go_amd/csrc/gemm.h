@@ -935,8 +935,9 @@ static int g_chunk_all_m = 64;     // up to here every projection does; above, o
 static int g_pass_interleave = 1;   // 64-row groups of one projection in ONE launch (key 13; 0 = one launch per group)
 static int g_chunk_min_tiles = 160;
 static int g_msplit_ks = 8;         // K split of the deferred-norm residual projections (nvl_set_tuning key 6)
-static int g_narrow_waves = 1024;   // waves per narrow-form launch (nvl_set_tuning key 5); in the model (weights cold from HBM) fewer,
-                                    // longer per-wave streams win: B=8 +8 %, B=16 +8 %, B=32 +3 % decode vs 4096
+static int g_narrow_waves = 2048;   // waves per narrow-form launch (nvl_set_tuning key 5).  Round-2 sweep on the final kernels
+                                    // (profiles/r02_narrow_waves_sweep.txt): 2048 vs 1024: B=1 +5.4 %, B=8 +5.0 %, B=16 +2.4 %,
+                                    // B=32 flat; 4096 = 2048.  (Round 1, before the activation-row mask: 1024 beat 4096 by 3-8 %.)
 static int g_wide_ksplit = 0;   // experiment (nvl_set_tuning key 4): K split of the wide form when groups <= 512
 static int g_x_mask = 1;            // nvl_set_tuning key 24: decode kernels skip the activation fetch of padded rows (M % 16 != 0)
 static int g_force_ntw = 0, g_force_ksplit = 0;   // tuning overrides (nvl_bench_gemm only)
