@@ -408,7 +408,8 @@ int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int 
  * weight-streaming projections (1, default) or sort + grouped GEMMs (0).  key 23: largest payload (rows of the residual
  * stream) the tensor-parallel P2P all-reduce sends one-shot; above it reduce-scatter + all-gather (default 64).
  * key 24: the decode GEMM kernels do not fetch the activation rows >= M of a padded 16-row tile (1, default).
- * Every call starts a new tuning epoch: captured decode graphs bake the tuning in and are re-captured.
+ * The settings are PROCESS-GLOBAL and unsynchronised (every model in the process sees them): set them from one thread
+ * while no forward call is running.  Every call starts a new tuning epoch: captured decode graphs bake the tuning in and are re-captured.
  * Returns the previous value. */
 int nvl_set_tuning(int key, int value);
 
