@@ -5,17 +5,17 @@
 //   MQA  mqa.go:47-99, :163-267                 group = nH (all heads share one K/V tile)
 // No repeatKVHeads copy, no Concatenate re-copy, no [nH,S,T] score tensor.
 //
-// bf16 kernel (product path): flash-style, MFMA 16x16x32 bf16, fp32 online softmax.
-// One workgroup = 4 waves = 64 "query rows" of one (sequence, kv head); a query row is a
-// (position, head-in-group) pair, position-major, so every head of a GQA/MQA group reuses the
-// same K/V tile from LDS.  Per wave 16 rows.  The products are issued transposed:
+// bf16 kernels (product path): flash-style, MFMA 16x16x32 bf16, fp32 online softmax.  A "query row" is a
+// (position, head-in-group) pair, position-major, so every head of a GQA/MQA group reuses the same K/V tile.
+// The products are issued transposed:
 //     S^T[key, q] = K[key, :] · Q[q, :]^T          (A = K tile rows,   B = Q rows, from registers)
 //     O^T[d,  q] += V^T[d, key] · P^T[key, q]      (A = V^T tile rows, B = P^T straight from the
 //                                                   S^T accumulators — no LDS, no shuffles)
-// so the softmax row (fixed q) lives on one lane column: the max/sum need two xor-shuffles, and the
-// O rescale is lane-local.  K and V are both kept ROW-MAJOR in HBM ([T][hd], the reference's own cache
-// layout, kv_cache.go:5-6): appends are contiguous rows, the prefill kernel gets the V^T operand from
-// its LDS image with transposed reads (ds_read_b64_tr_b16), the decode kernel reads V as whole rows.
+// so the softmax row (fixed q) lives on one lane column: the row maximum needs two cross-lane steps, the O rescale is
+// lane-local.  K and V are both kept ROW-MAJOR in HBM ([T][hd], the reference's own cache layout, kv_cache.go:5-6):
+// appends are contiguous rows; the V^T operand comes out of an LDS image of the row-major tile by transposed reads
+// (ds_read_b64_tr_b16) — in the prefill kernel the image is filled by LDS-DMA (8 waves, 256 query rows per workgroup),
+// in the decode kernel by the wave that loaded the rows (one new token per sequence, split-T over the waves).
 //
 // f32 kernel (parity mode): one workgroup per (query position, head); scores in LDS; plain fp32.
 #pragma once
@@ -124,7 +124,8 @@ __device__ __forceinline__ float rows_max(float x) {
 // HBM -> LDS by LDS-DMA through a 3-slot ring, two tiles ahead of the compute, with ONE barrier per tile:
 //     wait (my pieces of tile kt landed)  |  barrier  |  issue tile kt+2 into the slot tile kt-1 used  |  compute tile kt
 // (a slot is re-filled only after every wave passed the barrier that follows its last read; LDS-DMA is ordered by the
-// issuing wave's vmcnt + that barrier).  Two waves per SIMD: one wave's softmax VALU runs beside the other's MFMAs.
+// issuing wave's vmcnt + that barrier).  hd 64: four waves per SIMD (two workgroups per CU), so one wave's softmax VALU
+// runs beside another's MFMAs; hd 128: two.
 // ------------------------------------------------------------------------------------------
 template <int HD>
 __global__ __launch_bounds__(512, HD == 64 ? 4 : 2) void attn_prefill_bf16_kernel(AttnArgs p) {
