@@ -10,13 +10,15 @@
 // directly in this layout.
 //   * gemm_bf16_pp_kernel (prefill, >= 192 tiles of 256x256): the ping-pong form — two groups of four waves one phase
 //     apart, K in 32-wide stages through a 4-slot LDS ring filled by global_load_lds_dwordx4, so one group's fragment
-//     reads run beside the other's MFMAs.  MFMA-bound.
-//   * gemm_bf16_kernel (prefill, fewer tiles; MoE expert groups): lock-step tiles, by default 128x128x64 with 4 waves
+//     reads run beside the other's MFMAs.  MFMA-bound.  Also the grouped launch of the MoE prefill (GemmArgs::tile_map:
+//     an m-tile = an expert's 256-row segment of the expert-ordered row buffer).
+//   * gemm_bf16_kernel (prefill, fewer tiles; decode-sized MoE expert groups): lock-step tiles, by default 128x128x64 with 4 waves
 //     (2x2), each wave a 64x64 sub-tile as 4x4 v_mfma_f32_16x16x32_bf16 accumulators; operand blocks go HBM->LDS with
 //     global_load_lds_dwordx4 (one contiguous KiB per wave-instruction, no VGPR round trip), double-buffered; the LDS
 //     image is lane-linear so the fragment ds_read_b128s are bank-conflict-free with no swizzle.
 //   * gemm_skinny_bf16_kernel / gemm_skinny_wide_bf16_kernel (decode, M <= 64): weight-streaming, HBM-bound (see below);
-//     the residual projections also carry the deferred RMSNorm (GemmArgs::rs_out / rs_in).
+//     the residual projections also carry the deferred RMSNorm (GemmArgs::rs_out / rs_in); their MOE instantiations run
+//     a decode MoE block as two dense projections over all experts with the routing weights as a mask (GemmArgs::moe_gate).
 // The MFMA is issued "swapped" (weights as the A operand) so each lane ends up with 4 consecutive N
 // elements of one output row: 8/16-byte epilogue accesses, and the bf16 epilogues can write the
 // next GEMM's fragment-major operand directly.
@@ -34,7 +36,7 @@ enum GemmEpi {
     EPI_RESID = 1,   // X += alpha * (acc (+bias))      X fp32, in place   (generic_model.go:320-326)
     EPI_SWIGLU = 2,  // C[m, f] = silu(gate) * up        W rows interleaved (transformer.go:50-66)
     EPI_GELU = 3,    // C = gelu_tanh(acc + bias)                           (transformer.go:67-78)
-    EPI_QKV = 4,     // fused QKV projection epilogue (head_dim 64): bias, RoPE on Q and K (rope.go:153-205),
+    EPI_QKV = 4,     // fused QKV projection epilogue (head_dim 64 / 128): bias, RoPE on Q and K (rope.go:153-205),
                      // Q -> q buffer, K and V -> their KV slabs [pos][hd]  (replaces the fp32 qkv
                      // round trip + rope_kv_kernel in prefill; Concatenate tensor.go:283-321)
 };
