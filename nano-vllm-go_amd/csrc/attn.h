@@ -47,7 +47,13 @@ struct AttnArgs {
     int qkv_stride;
     const float* cos_t;   // [max_seq][HD] or NULL
     const float* sin_t;
+    // decode kernel with gridDim.z > 1 (keys split over workgroups): workgroup z leaves its partial result here —
+    // [(seq * nKV + kvh) * gridDim.z + z] records of {O^T [HD/16][64 lanes] f32x4 (unnormalised), m[16], l[16]} — and
+    // takes a ticket from part_cnt[seq * nKV + kvh]; the workgroup that draws the last one combines them in z order.
+    float* part;
+    int32_t* part_cnt;    // zero between launches
 };
+template <int HD> constexpr int attn_part_floats() { return (HD / 16) * 64 * 4 + 32; }
 
 // index of the KV block that holds key `key`
 __device__ __forceinline__ int kv_block_index(const AttnArgs& p, int key) { return p.bs_shift >= 0 ? (key >> p.bs_shift) : key / p.Tmax; }
@@ -384,6 +390,35 @@ __device__ __forceinline__ void rope_pair8(const float* row, const float* cs, co
     }
 }
 
+// combine of a split decode launch: the nsplit partial results of (sequence, kv head), in workgroup order whichever
+// workgroup runs it.  One wave, the lanes fq < group; lane (fq = head in group, fg) as in the kernel's own combine.
+template <int HD>
+__device__ __forceinline__ void attn_decode_merge(const AttnArgs& p, int seq, int kvh, int nsplit, int lane) {
+    constexpr int DT = HD / 16;
+    const int fq = lane & 15, fg = lane >> 4;
+    const float* rec0 = p.part + (int64_t)(seq * p.nKV + kvh) * nsplit * attn_part_floats<HD>();
+    float mstar = -INFINITY;
+    for (int z = 0; z < nsplit; z++) mstar = fmaxf(mstar, rec0[(int64_t)z * attn_part_floats<HD>() + DT * 256 + fq]);
+    float L = 0.f;
+    f32x4 O[DT];
+#pragma unroll
+    for (int d = 0; d < DT; d++) O[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < nsplit; z++) {
+        const float* rec = rec0 + (int64_t)z * attn_part_floats<HD>();
+        const float mz = rec[DT * 256 + fq];
+        if (mz == -INFINITY) continue;                 // that workgroup had no tile
+        const float sc = __builtin_amdgcn_exp2f(mz - mstar);
+        L += rec[DT * 256 + 16 + fq] * sc;
+#pragma unroll
+        for (int d = 0; d < DT; d++) O[d] += ((const f32x4*)rec)[d * 64 + lane] * sc;
+    }
+    const float inv = 1.0f / L;
+    const int tok = p.seq_tok_start[seq], head = kvh * p.group + fq;
+#pragma unroll
+    for (int d = 0; d < DT; d++)
+        act_store4<bf16_t>((bf16_t*)p.out, tok, head * HD + d * 16 + fg * 4, p.out_stride, O[d] * inv);
+}
+
 template <int HD, int NW, bool FUSED>
 __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
     constexpr int KS = HD / 32, DT = HD / 16, HALF = HD / 2, CPR = HD / 8, KPI = 64 / CPR, NVL = 64 / KPI;
@@ -404,6 +439,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
     char* vimg = smem + wave * TILE_BYTES;
     bf16x8 qf[KS];
     const int n_kt = pos0 / 64 + 1;
+    // key tiles are dealt round-robin over "virtual waves": the NW waves of each of the gridDim.z workgroups of this
+    // (sequence, kv head).  gridDim.z > 1 (long contexts in small batches: one workgroup would pull the whole K/V of its
+    // head through one CU, ~50 GB/s) leaves partial results for attn_decode_merge_kernel.
+    const int vw = blockIdx.z * NW + wave, nvw = NW * gridDim.z;
     // FUSED: the new token's K row (RoPE applied) as this lane's MFMA operand chunks, and chunk dch of its V row
     bf16x8 knew[KS];
     bf16x8 vnew8;
@@ -442,16 +481,16 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
     // the block ids of this wave's first tiles do not depend on the sequence length: fetch them beside it, not after it
     int first_blk[NT2];
 #pragma unroll
-    for (int h = 0; h < NT2; h++) first_blk[h] = tbl[min(kv_block_index(p, (wave + h * NW) * 64), p.tbl_stride - 1)];
+    for (int h = 0; h < NT2; h++) first_blk[h] = tbl[min(kv_block_index(p, (vw + h * nvw) * 64), p.tbl_stride - 1)];
     bf16x8 kf[NT2][4][KS];
     bf16x8 vch[NT2][NVL];
-    for (int kt0 = wave; kt0 < n_kt; kt0 += NT2 * NW) {
+    for (int kt0 = vw; kt0 < n_kt; kt0 += NT2 * nvw) {
 #pragma unroll
         for (int h = 0; h < NT2; h++) {
-            const int kt = kt0 + h * NW;
+            const int kt = kt0 + h * nvw;
             if (kt >= n_kt) continue;
             const int bi = kv_block_index(p, kt * 64), krow0 = kt * 64 - bi * p.Tmax;     // the KV block holding this tile
-            const int blk = kt0 == wave ? first_blk[h] : tbl[bi];
+            const int blk = kt0 == vw ? first_blk[h] : tbl[bi];
             const int64_t blk_off = (int64_t)blk * p.slot_stride + ((int64_t)kvh * p.Tmax + krow0) * HD;
             const bf16_t* kbase = (const bf16_t*)p.kcache + blk_off;
             const bf16_t* vbase = (const bf16_t*)p.vcache + blk_off;
@@ -468,7 +507,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
         float tmax = -INFINITY;
 #pragma unroll
         for (int h = 0; h < NT2; h++) {
-            const int kt = kt0 + h * NW;
+            const int kt = kt0 + h * nvw;
             if (kt >= n_kt) {
 #pragma unroll
                 for (int t = 0; t < 4; t++) s[h][t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -526,7 +565,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
         // MFMA operand (ds_read_b64_tr_b16); a wave's LDS accesses execute in order, so no barrier ----
 #pragma unroll
         for (int h = 0; h < NT2; h++) {
-            if (kt0 + h * NW >= n_kt) continue;
+            if (kt0 + h * nvw >= n_kt) continue;
 #pragma unroll
             for (int i = 0; i < NVL; i++) *(bf16x8*)(vimg + w_base[i & 1] + i * (16 * KPI * CPR)) = vch[h][i];
 #pragma unroll
@@ -546,7 +585,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
             }
         }
     }
-    if (FUSED) {
+    if (FUSED && blockIdx.z == 0) {
         // append the new key/value to the slabs for the following steps — after every load of this step (which used
         // the register copies), so the loads above are not ordered behind these stores
         int nblk, nrow;
@@ -575,13 +614,34 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
     f32x4 O[DT];
 #pragma unroll
     for (int d = 0; d < DT; d++) O[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (mstar > -INFINITY) {       // (a workgroup of a split launch may have had no tile at all)
 #pragma unroll
-    for (int w = 0; w < NW; w++) {
-        const float sc = __builtin_amdgcn_exp2f(red_m[w][fq] - mstar);   // idle waves: exp2(-inf) = 0
-        L += red_l[w][fq] * sc;
-        const f32x4* wo = (const f32x4*)(smem + w * TILE_BYTES);
+        for (int w = 0; w < NW; w++) {
+            const float sc = __builtin_amdgcn_exp2f(red_m[w][fq] - mstar);   // idle waves: exp2(-inf) = 0
+            L += red_l[w][fq] * sc;
+            const f32x4* wo = (const f32x4*)(smem + w * TILE_BYTES);
 #pragma unroll
-        for (int d = 0; d < DT; d++) O[d] += wo[d * 64 + lane] * sc;
+            for (int d = 0; d < DT; d++) O[d] += wo[d * 64 + lane] * sc;
+        }
+    }
+    if (gridDim.z > 1) {
+        float* rec = p.part + ((int64_t)(seq * p.nKV + kvh) * gridDim.z + blockIdx.z) * attn_part_floats<HD>();
+#pragma unroll
+        for (int d = 0; d < DT; d++) ((f32x4*)rec)[d * 64 + lane] = O[d];
+        if (fg == 0) { rec[DT * 256 + fq] = mstar; rec[DT * 256 + 16 + fq] = L; }
+        // Last arriver combines (no second launch: a merge kernel cost 5-7 us of the 8-11 the split saves).  Release my
+        // record device-wide (the workgroups of a pair may sit on different XCDs, whose L2s are not coherent), draw a
+        // ticket, and if it is the last one acquire the others' records.  The order of the sum is z order regardless.
+        __threadfence();
+        int ticket = 0;
+        int32_t* cnt = p.part_cnt + seq * p.nKV + kvh;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket != (int)gridDim.z - 1) return;
+        __threadfence();
+        attn_decode_merge<HD>(p, seq, kvh, gridDim.z, lane);
+        if (lane == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // for the next launch
+        return;
     }
     const float inv = 1.0f / L;
 #pragma unroll

@@ -114,6 +114,8 @@ struct nvl_model {
     float* qkv = nullptr;        // fp32 [Mmax][n_qkv]
     void* q = nullptr;           // ActT [Mmax][nH*hd]
     void* attn_out = nullptr;    // ActT [Mmax][nH*hd]
+    float* attn_part = nullptr;  // bf16: partial results of a decode attention whose keys are split over workgroups (attn.h AttnArgs::part)
+    int32_t* attn_part_cnt = nullptr;   // ... and their arrival tickets per (sequence, kv head)
     void* hbuf = nullptr;        // ActT [Mmax][F]   (MoE: [Mmax*k][I])
     float* h2 = nullptr;         // fp32 [Mmax][2F]  (f32 mode un-fused gate|up; MoE f32 too)
     void* xn_last = nullptr;     // ActT [rows][H]

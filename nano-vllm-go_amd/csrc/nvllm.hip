@@ -17,6 +17,7 @@
 using namespace nvl;
 
 static thread_local std::string g_create_err;
+constexpr int ATTN_SPLIT_MAX_PAIRS = 16, ATTN_SPLIT_MAX = 8;     // split decode attention: (sequence, kv head) pairs a launch may have; most workgroups per pair
 constexpr int MOE_DOWN_SLICES = 16;   // at most this many K slices (workgroups per column tile) in the dense-masked MoE down projection
 static inline int moe_down_slices(int E) { int s = MOE_DOWN_SLICES; while (s > 1 && E % s) s--; return s; }   // a whole number of experts per slice
 
@@ -303,7 +304,7 @@ extern "C" void nvl_destroy(nvl_model* m) {
     }
     if (m->lm_head && m->lm_head != m->g[NVL_T_TOK_EMB].p && m->lm_head != m->g[NVL_T_LM_HEAD].p) dfree(m->lm_head);
     dfree(m->rope_cos); dfree(m->rope_sin); dfree(m->kcache); dfree(m->vcache);
-    dfree(m->x); dfree(m->xn); dfree(m->qkv); dfree(m->q); dfree(m->attn_out); dfree(m->hbuf); dfree(m->h2);
+    dfree(m->x); dfree(m->xn); dfree(m->qkv); dfree(m->q); dfree(m->attn_out); dfree(m->attn_part); dfree(m->attn_part_cnt); dfree(m->hbuf); dfree(m->h2);
     dfree(m->xn_last); dfree(m->logits); dfree(m->argmax_dev); dfree(m->argmax_pval); dfree(m->argmax_pidx); dfree(m->router_logits); dfree(m->expert_ids);
     dfree(m->expert_w); dfree(m->seg_start); dfree(m->moe_counts); dfree(m->moe_cursor); dfree(m->moe_tile_map); dfree(m->moe_n_mtiles); dfree(m->perm_token); dfree(m->slot_of); dfree(m->moe_eo); dfree(m->moe_xg);
     dfree(m->meta_dev); dfree(m->hidden); dfree(m->sk_part); dfree(m->tp_part); dfree(m->ring); dfree(m->rs_part);
@@ -748,6 +749,11 @@ extern "C" int nvl_finalize(nvl_model* m) {
     m->qkv = dmalloc<float>(Mmax * m->n_qkv);
     m->q = dmalloc_bytes(Mmax * qw * (int64_t)m->wsize);
     m->attn_out = dmalloc_bytes(Mp * qw * (int64_t)m->wsize);
+    if (!m->f32 && m->group <= 16 && (m->hd == 64 || m->hd == 128)) {     // partial results of a split decode attention (attn.h)
+        m->attn_part = dmalloc<float>((int64_t)ATTN_SPLIT_MAX_PAIRS * ATTN_SPLIT_MAX * (m->hd == 64 ? attn_part_floats<64>() : attn_part_floats<128>()));
+        m->attn_part_cnt = dmalloc<int32_t>(ATTN_SPLIT_MAX_PAIRS);
+        NVL_HIP(hipMemset(m->attn_part_cnt, 0, ATTN_SPLIT_MAX_PAIRS * sizeof(int32_t)));
+    }
     const int64_t k = c.use_moe ? c.num_experts_per_tok : 1;
     m->hbuf = dmalloc_bytes(round_up(Mmax * k, 64) * m->F * (int64_t)m->wsize);
     NVL_HIP(hipMemsetAsync(m->xn, 0, (size_t)(Mp * H) * m->wsize, m->stream));
@@ -1031,15 +1037,28 @@ static int g_use_graphs = 1;   // nvl_set_tuning key 21: hipGraph replay of deco
 static int g_tune_epoch = 0;   // bumped by every nvl_set_tuning: captured graphs bake the tuning in (part of their key)
 static int g_attn_nw = 0;      // nvl_set_tuning key 15: waves per decode-attention workgroup (0 = from the context length, 2, 4, 8)
 static int g_attn_tq2 = 1;     // nvl_set_tuning key 10: unused since round 2 (the prefill kernel always keeps two sub-tiles per wave)
-// waves per decode-attention workgroup for the batch being enqueued (also part of a captured graph's key)
-int decode_attn_waves(const nvl_model* m, int n_seqs) {
+static int g_attn_split = 1;   // nvl_set_tuning key 25: split a decode attention's keys over up to 8 workgroups per (sequence, kv head) (0 = never)
+// Launch shape of the decode attention for the batch being enqueued (also part of a captured graph's key): waves per
+// workgroup | workgroups per (sequence, kv head) << 8.
+// Split: a workgroup pulls all K/V of its (sequence, kv head) through ONE CU; with one or two sequences and a long context
+// (B = 1 at 2048 keys: 8 workgroups x 512 KB) that, not HBM, is the time.  Then the key tiles are dealt over up to 8
+// workgroups of 2 waves each; the last of them to finish combines the partial results (attn.h).  Measured (decode ms/step,
+// Llama-3.2-1B, 2048 / 1024 keys): B=1 0.891 -> 0.811 / 0.808 -> 0.780, B=2 0.893 -> 0.834 / 0.869 -> 0.792; from B=4 on
+// (32 pairs: 256 workgroups, each with a device-scope release fence) it is a loss (B=8: 0.96 -> 1.13), hence <= 16 pairs.
+int decode_attn_cfg(const nvl_model* m, int n_seqs) {
     const int n_kt = m->ctx_hint > 0 ? (m->ctx_hint - 1) / 64 + 1 : 1 << 20;
     const int per_wave = m->hd == 64 ? 2 : 1;
     const int wgs = m->nKV * n_seqs;
+    if (g_attn_split && !g_attn_nw && m->attn_part && m->ctx_hint > 0 && wgs <= ATTN_SPLIT_MAX_PAIRS && n_kt >= 16) {
+        const int want = cdiv(n_kt, 2 * per_wave);                       // workgroups of 2 waves that get a full round each
+        const int ns = std::min(want, ATTN_SPLIT_MAX);
+        if (ns >= 2) return 2 | (ns << 8);
+    }
     const int cap = wgs >= 512 ? 2 : (wgs >= 320 ? 4 : 8);
     const int nw = n_kt <= 2 * per_wave ? 2 : (n_kt <= 4 * per_wave ? 4 : 8);
-    return g_attn_nw ? g_attn_nw : std::min(nw, cap);
+    return (g_attn_nw ? g_attn_nw : std::min(nw, cap)) | (1 << 8);
 }
+int decode_attn_waves(const nvl_model* m, int n_seqs) { return decode_attn_cfg(m, n_seqs); }   // (graph keys: the whole shape)
 void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, double flops, bool fused_qkv = false) {
     AttnArgs a{};
     a.q = m->q; a.q_stride = m->nH * m->hd;
@@ -1057,12 +1076,14 @@ void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, do
         const size_t lds = (size_t)m->Tmax * 4;
         hipLaunchKernelGGL(attn_f32_kernel, dim3(max_len, m->nH, n_seqs), dim3(256), lds, m->stream, a, m->hd);
     } else if (max_len == 1 && m->group <= 16) {
-        dim3 grid(m->nKV, n_seqs);
+        const int cfg = decode_attn_cfg(m, n_seqs), nsplit = cfg >> 8;
+        dim3 grid(m->nKV, n_seqs, nsplit);
+        a.part = m->attn_part; a.part_cnt = m->attn_part_cnt;
         // waves per workgroup: each wave takes NT2 key tiles per round trip (2 for hd 64, 1 for hd 128).  Short contexts
         // need fewer than 8 waves (idle waves still cost LDS and a slot in the final merge), and once the grid alone
         // fills the chip (>= 2 workgroups per CU) fewer, longer-running waves stream better than many short ones
         // (profiles/r01g_decode_attention_waves.txt).  ctx_hint = the batch's longest context when the caller knows it.
-        const int nw = decode_attn_waves(m, n_seqs);
+        const int nw = cfg & 255;
         if (fused_qkv) {   // RoPE + KV append + attention in one launch, straight from the QKV projection's fp32 output
             a.qkv = m->qkv; a.qkv_stride = m->n_qkv; a.cos_t = m->rope_cos; a.sin_t = m->rope_sin;
         }

@@ -351,3 +351,58 @@ def test_graph_replayed_decode_is_bit_identical_to_eager(gpu, oracle, family):
         assert np.array_equal(a, b)
     assert np.array_equal(fused_e, fused_g)
     hm.close()
+
+
+@pytest.mark.parametrize("family,hd", [("llama", 64), ("llama", 128), ("falcon", 64)])
+def test_long_context_decode_splits_keys_over_workgroups(gpu, oracle, family, hd):
+    """Decode over >= 1024 cached keys in a small batch deals the key tiles over several workgroups per (sequence,
+    kv head) and combines their partial softmax results in a second launch (attn.h gridDim.z, attn_decode_merge_kernel):
+    two sequences (1100 and 70 cached tokens: the short one leaves most workgroups without a tile), stepwise and through
+    the fused greedy loop, against the oracle and against the unsplit kernel (key 25 = 0)."""
+    over = dict(max_seq_len=1280)
+    if hd == 128:
+        over.update(head_dim=128, hidden=512)
+    cfg, om, _ = build(gpu, oracle, family, "bf16", **over)
+    w = gpu.synth.make_weights(cfg, seed=7, scale=0.05)
+    hm = gpu.HipTransformerModel(cfg, w, precision="bf16", max_seqs=4, max_batch_tokens=1280)
+    r = np.random.default_rng(31)
+    prompts = [r.integers(0, cfg["vocab_size"], n).tolist() for n in (1100, 70)]
+    forced = [r.integers(0, cfg["vocab_size"], 4).tolist() for _ in prompts]
+    kvs = [om.new_cache() for _ in prompts]
+    for i in range(2):
+        om.forward_with_cache(prompts[i], kvs[i], 0)
+    logits = {}
+    for split, ids in ((1, [0, 1]), (0, [2, 3])):           # the same two sequences in two pairs of KV slots
+        old = gpu.lib().nvl_set_tuning(25, split)
+        try:
+            for i in ids:
+                hm.seq_reset(i)
+            hm.forward_batch(ids, prompts, [0, 0], want_logits=False)
+            out = []
+            for s in range(4):
+                lg, _ = hm.forward_batch(ids, [[forced[i][s]] for i in range(2)], [len(prompts[i]) + s for i in range(2)])
+                out.append(lg.copy())
+            logits[split] = out
+            if split:                                       # ... and the fused greedy loop over the split kernel
+                for i in ids:
+                    hm.seq_reset(i)
+                _, first = hm.forward_batch(ids, prompts, [0, 0], want_logits=False)
+                fused = hm.decode_greedy(ids, first, 3)
+                for i in ids:
+                    hm.seq_reset(i)
+                _, cur = hm.forward_batch(ids, prompts, [0, 0], want_logits=False)
+                for s in range(3):
+                    _, cur = hm.forward_batch(ids, [[int(t)] for t in cur], [len(prompts[i]) + s for i in range(2)], want_logits=False)
+                    assert (fused[s] == cur).all()
+        finally:
+            gpu.lib().nvl_set_tuning(25, old)
+    differs = False
+    for s in range(4):
+        for i in range(2):
+            want = om.forward_with_cache([forced[i][s]], kvs[i], len(prompts[i]) + s)[-1]
+            assert rel_err(logits[1][s][i], want) <= 1.5e-2, (s, i)
+            assert rel_err(logits[0][s][i], want) <= 1.5e-2, (s, i)
+            assert rel_err(logits[1][s][i], logits[0][s][i]) <= 1e-2, (s, i)     # (P is rounded to bf16 against another running maximum)
+            differs |= not np.array_equal(logits[1][s][i], logits[0][s][i])
+    assert differs          # (the split launch sums in another order: identical bits would mean it never ran)
+    hm.close()
