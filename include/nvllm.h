@@ -407,8 +407,8 @@ int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int 
  * key 21: hipGraph replay of decode passes (1, default; 0 = every launch eager).  key 22: decode MoE as two dense-masked
  * weight-streaming projections (1, default) or sort + grouped GEMMs (0).  key 23: largest payload (rows of the residual
  * stream) the tensor-parallel P2P all-reduce sends one-shot; above it reduce-scatter + all-gather (default 64).
- * key 25: a decode attention over >= 1024 keys in a tiny batch (<= 16 (sequence, kv head) pairs: Llama B <= 2) deals its key
- * tiles over up to 8 workgroups per pair, the last of which combines the partial results (1, default; 0 = one workgroup per pair).
+ * key 25: a decode attention over >= 1024 keys in a tiny batch (<= 32 (sequence, kv head) pairs: Llama B <= 4) deals its key
+ * tiles over up to 8 workgroups per pair (<= 128 in all), the last of which combines the partial results (1, default; 0 = never).
  * key 24: the decode GEMM kernels do not fetch the activation rows >= M of a padded 16-row tile (1, default).
  * The settings are PROCESS-GLOBAL and unsynchronised (every model in the process sees them): set them from one thread
  * while no forward call is running.  Every call starts a new tuning epoch: captured decode graphs bake the tuning in and are re-captured.

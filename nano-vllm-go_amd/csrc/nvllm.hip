@@ -17,7 +17,7 @@
 using namespace nvl;
 
 static thread_local std::string g_create_err;
-constexpr int ATTN_SPLIT_MAX_PAIRS = 16, ATTN_SPLIT_MAX = 8;     // split decode attention: (sequence, kv head) pairs a launch may have; most workgroups per pair
+constexpr int ATTN_SPLIT_MAX_PAIRS = 32, ATTN_SPLIT_MAX = 8;     // split decode attention: (sequence, kv head) pairs a launch may have; most workgroups per pair
 constexpr int MOE_DOWN_SLICES = 16;   // at most this many K slices (workgroups per column tile) in the dense-masked MoE down projection
 static inline int moe_down_slices(int E) { int s = MOE_DOWN_SLICES; while (s > 1 && E % s) s--; return s; }   // a whole number of experts per slice
 
@@ -1040,18 +1040,20 @@ static int g_attn_tq2 = 1;     // nvl_set_tuning key 10: unused since round 2 (t
 static int g_attn_split = 1;   // nvl_set_tuning key 25: split a decode attention's keys over up to 8 workgroups per (sequence, kv head) (0 = never)
 // Launch shape of the decode attention for the batch being enqueued (also part of a captured graph's key): waves per
 // workgroup | workgroups per (sequence, kv head) << 8.
-// Split: a workgroup pulls all K/V of its (sequence, kv head) through ONE CU; with one or two sequences and a long context
+// Split: a workgroup pulls all K/V of its (sequence, kv head) through ONE CU; with a few sequences and a long context
 // (B = 1 at 2048 keys: 8 workgroups x 512 KB) that, not HBM, is the time.  Then the key tiles are dealt over up to 8
-// workgroups of 2 waves each; the last of them to finish combines the partial results (attn.h).  Measured (decode ms/step,
-// Llama-3.2-1B, 2048 / 1024 keys): B=1 0.891 -> 0.811 / 0.808 -> 0.780, B=2 0.893 -> 0.834 / 0.869 -> 0.792; from B=4 on
-// (32 pairs: 256 workgroups, each with a device-scope release fence) it is a loss (B=8: 0.96 -> 1.13), hence <= 16 pairs.
+// workgroups of 2 waves each; the last of them to finish combines the partial results (attn.h).  Every workgroup of a
+// split launch pays a device-scope release fence, so the launch stays within 128 workgroups.  Measured (decode ms/step,
+// Llama-3.2-1B, 2048 / 1024 keys): B=1 0.891 -> 0.811 / 0.808 -> 0.780, B=2 0.893 -> 0.834 / 0.869 -> 0.792, B=4 (4
+// workgroups per pair) 0.924 -> 0.883 / 0.812 -> 0.817 (hence from 2048 keys on above 16 pairs); B=8 loses either way
+// (2 workgroups per pair 0.96 -> 0.99, 8 per pair -> 1.13).
 int decode_attn_cfg(const nvl_model* m, int n_seqs) {
     const int n_kt = m->ctx_hint > 0 ? (m->ctx_hint - 1) / 64 + 1 : 1 << 20;
     const int per_wave = m->hd == 64 ? 2 : 1;
     const int wgs = m->nKV * n_seqs;
     if (g_attn_split && !g_attn_nw && m->attn_part && m->ctx_hint > 0 && wgs <= ATTN_SPLIT_MAX_PAIRS && n_kt >= 16) {
         const int want = cdiv(n_kt, 2 * per_wave);                       // workgroups of 2 waves that get a full round each
-        const int ns = std::min(want, ATTN_SPLIT_MAX);
+        const int ns = (wgs > 16 && n_kt < 32) ? 1 : std::min(std::min(want, ATTN_SPLIT_MAX), 128 / wgs);
         if (ns >= 2) return 2 | (ns << 8);
     }
     const int cap = wgs >= 512 ? 2 : (wgs >= 320 ? 4 : 8);
