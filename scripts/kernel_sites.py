@@ -85,7 +85,11 @@ def label_passes(rows, name_key="Kernel_Name"):
         passes.append(cur)
     passes = [p for p in passes if any("gemm" in r["kname"] for r in p)]
     for p in passes:
-        phase = "prefill" if any("attn_prefill" in r["kname"] or "attn_f32" in r["kname"] for r in p) and \
+        # a decode step of an MQA model (Falcon: 71 query heads per KV head) runs the prefill attention kernel too (the decode
+        # kernel takes groups of <= 16 heads): such a pass is told from a prefill by its projections, which are all on the
+        # weight-streaming decode kernels
+        tiles = any("gemm_bf16_pp_kernel" in r["kname"] or "gemm_bf16_kernel" in r["kname"] or "gemm_f32_kernel" in r["kname"] for r in p)
+        phase = "prefill" if any("attn_prefill" in r["kname"] or "attn_f32" in r["kname"] for r in p) and tiles and \
             not any("attn_decode" in r["kname"] for r in p) else "decode"
         last = None
         for i, r in enumerate(p):
