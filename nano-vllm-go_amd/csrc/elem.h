@@ -521,8 +521,8 @@ __device__ __forceinline__ void moe_route_row(const float* __restrict__ logits_r
     // argmax visits them (moe.go:75-92).  64 register broadcasts instead of top_k dependent butterfly reductions.
     int rank = 0;
     const int pbits = __builtin_bit_cast(int, prob);
-#pragma unroll
-    for (int j = 0; j < 64; j++) {
+#pragma unroll 8
+    for (int j = 0; j < E; j++) {       // (lanes >= E hold -1: they never outrank an expert)
         const float pj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pbits, j));
         rank += (pj > prob || (pj == prob && j < lane)) ? 1 : 0;
     }
@@ -561,8 +561,8 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const float* __restrict__
     const float prob = (lane < E) ? e / s : -1.f;
     int rank = 0;                                   // as moe_route_row: larger first, ties to the lower index
     const int pbits = __builtin_bit_cast(int, prob);
-#pragma unroll
-    for (int j = 0; j < 64; j++) {
+#pragma unroll 8
+    for (int j = 0; j < E; j++) {       // (lanes >= E hold -1: they never outrank an expert)
         const float pj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pbits, j));
         rank += (pj > prob || (pj == prob && j < lane)) ? 1 : 0;
     }
