@@ -18,7 +18,7 @@ using namespace nvl;
 
 static thread_local std::string g_create_err;
 constexpr int ATTN_SPLIT_MAX_PAIRS = 32, ATTN_SPLIT_MAX = 8;     // split decode attention: (sequence, kv head) pairs a launch may have; most workgroups per pair
-constexpr int MOE_DOWN_SLICES = 16;   // at most this many K slices (workgroups per column tile) in the dense-masked MoE down projection
+constexpr int MOE_DOWN_SLICES = 4;    // at most this many K slices (workgroups per column tile) in the dense-masked MoE down projection
 static inline int moe_down_slices(int E) { int s = MOE_DOWN_SLICES; while (s > 1 && E % s) s--; return s; }   // a whole number of experts per slice
 
 namespace {
