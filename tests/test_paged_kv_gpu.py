@@ -172,3 +172,39 @@ def test_fused_greedy_loop_over_block_tables(gpu, oracle, precision):
     with pytest.raises(gpu.NvlError):                      # tables that stop short of the generated positions
         paged.decode_greedy_paged(first, pos, steps, [s.block_table for s in seqs])
     slab.close(); paged.close()
+
+
+def test_long_context_paged_decode_equals_slab(gpu, oracle):
+    """>= 1024 cached keys in a tiny batch: the decode attention deals its key tiles over several workgroups per
+    (sequence, kv head) (attn.h gridDim.z) — through block tables of scattered 64-token blocks exactly as through a slab:
+    the same tiles go to the same workgroups, so the logits are identical bit for bit."""
+    cfg, om, slab, paged = models(gpu, oracle, "llama", "bf16", blocks=48, max_seq_len=1280)
+    slab.close(); paged.close()
+    w = gpu.synth.make_weights(cfg, seed=7, scale=0.05)
+    slab = gpu.HipTransformerModel(cfg, w, precision="bf16", max_seqs=4, max_batch_tokens=1280)
+    paged = gpu.HipTransformerModel(cfg, w, precision="bf16", max_seqs=4, max_batch_tokens=1280, kv_num_blocks=48,
+                                    kv_block_size=BS)
+    r = np.random.default_rng(5)
+    bm = BlockManager(48, BS)
+    bm.free = list(r.permutation(48))
+    seqs = [gpu.Sequence(seq_id=i, token_ids=r.integers(0, cfg["vocab_size"], n).tolist(), block_size=BS)
+            for i, n in enumerate((1090, 130))]
+    for s in seqs:
+        bm.allocate(s)
+        slab.seq_reset(s.seq_id)
+    lg_p, am_p = paged.forward_paged([s.token_ids for s in seqs], [0, 0], [s.block_table for s in seqs])
+    lg_s, am_s = slab.forward_batch([0, 1], [s.token_ids for s in seqs], [0, 0])
+    assert np.array_equal(lg_p, lg_s)
+    for step in range(6):
+        for s, t in zip(seqs, am_p):
+            s.append_token(int(t))
+            bm.may_append(s)
+        pos = [len(s) - 1 for s in seqs]
+        lg_p, am_p = paged.forward_paged([[s.token_ids[-1]] for s in seqs], pos, [s.block_table for s in seqs])
+        lg_s, am_s = slab.forward_batch([0, 1], [[s.token_ids[-1]] for s in seqs], pos)
+        assert np.array_equal(lg_p, lg_s) and np.array_equal(am_p, am_s), step
+    kv = om.new_cache()
+    om.forward_with_cache(seqs[0].token_ids[:-1], kv, 0)
+    want = om.forward_with_cache([seqs[0].token_ids[-1]], kv, len(seqs[0]) - 1)[-1]
+    assert rel_err(lg_p[0], want) <= TOL["bf16"]
+    slab.close(); paged.close()
