@@ -48,8 +48,8 @@ struct AttnArgs {
     const float* cos_t;   // [max_seq][HD] or NULL
     const float* sin_t;
     // decode kernel with gridDim.z > 1 (keys split over workgroups): workgroup z leaves its partial result here —
-    // [(seq * nKV + kvh) * gridDim.z + z] records of {O^T [HD/16][64 lanes] f32x4 (unnormalised), m[16], l[16]} — and
-    // takes a ticket from part_cnt[seq * nKV + kvh]; the workgroup that draws the last one combines them in z order.
+    // [(seq * gridDim.x + blockIdx.x) * gridDim.z + z] records of {O^T [HD/16][64 lanes] f32x4 (unnormalised), m[16], l[16]} — and
+    // takes a ticket from part_cnt[seq * gridDim.x + blockIdx.x]; the workgroup that draws the last one combines them in z order.
     float* part;
     int32_t* part_cnt;    // zero between launches
 };
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(512, HD == 64 ? 4 : 2) void attn_prefill_bf16_kerne
 template <int HD> constexpr int attn_prefill_lds_bytes() { return 3 * 2 * 64 * HD * 2; }
 
 // ------------------------------------------------------------------------------------------
-// bf16 decode kernel (one new token per sequence, group <= 16 query heads per kv head).
+// bf16 decode kernel (one new token per sequence; 16 query heads of a kv head's group per workgroup).
 // HBM/latency-bound KV read: one workgroup per (sequence, kv head); its NW waves take the 64-key tiles round-robin
 // (split-T inside the workgroup), each with its own online-softmax state; nothing is shared between waves, so there
 // is no LDS staging and no barrier in the loop, and the NW partial results are merged once through LDS
@@ -390,13 +390,13 @@ __device__ __forceinline__ void rope_pair8(const float* row, const float* cs, co
     }
 }
 
-// combine of a split decode launch: the nsplit partial results of (sequence, kv head), in workgroup order whichever
-// workgroup runs it.  One wave, the lanes fq < group; lane (fq = head in group, fg) as in the kernel's own combine.
+// combine of a split decode launch: the nsplit partial results of one (sequence, kv head, query tile), in workgroup order
+// whichever workgroup runs it.  One wave, the lanes of real heads; lane (fq, fg) as in the kernel's own combine.
 template <int HD>
-__device__ __forceinline__ void attn_decode_merge(const AttnArgs& p, int seq, int kvh, int nsplit, int lane) {
+__device__ __forceinline__ void attn_decode_merge(const AttnArgs& p, int pair, int tok, int head, int nsplit, int lane) {
     constexpr int DT = HD / 16;
     const int fq = lane & 15, fg = lane >> 4;
-    const float* rec0 = p.part + (int64_t)(seq * p.nKV + kvh) * nsplit * attn_part_floats<HD>();
+    const float* rec0 = p.part + (int64_t)pair * nsplit * attn_part_floats<HD>();
     float mstar = -INFINITY;
     for (int z = 0; z < nsplit; z++) mstar = fmaxf(mstar, rec0[(int64_t)z * attn_part_floats<HD>() + DT * 256 + fq]);
     float L = 0.f;
@@ -413,7 +413,6 @@ __device__ __forceinline__ void attn_decode_merge(const AttnArgs& p, int seq, in
         for (int d = 0; d < DT; d++) O[d] += ((const f32x4*)rec)[d * 64 + lane] * sc;
     }
     const float inv = 1.0f / L;
-    const int tok = p.seq_tok_start[seq], head = kvh * p.group + fq;
 #pragma unroll
     for (int d = 0; d < DT; d++)
         act_store4<bf16_t>((bf16_t*)p.out, tok, head * HD + d * 16 + fg * 4, p.out_stride, O[d] * inv);
@@ -427,15 +426,18 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [NW] wave-private V images (later: the partial O^T)
     __shared__ float red_m[NW][16];
     __shared__ float red_l[NW][16];
-    const int seq = blockIdx.y, kvh = blockIdx.x;
+    // grid.x = kv head x query tile: a workgroup takes 16 of the group's query heads (GQA / MHA: one tile; Falcon's MQA:
+    // 71 heads = 5 tiles that stream the same K/V — it is tiny next to the weights — from L2)
+    const int QT = (p.group + 15) >> 4;
+    const int seq = blockIdx.y, kvh = blockIdx.x / QT, qt = blockIdx.x - kvh * QT;
     const int32_t* tbl = p.blk_table + (int64_t)seq * p.tbl_stride;
     const int tok = p.seq_tok_start[seq], pos0 = p.seq_pos[seq];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fq = lane & 15, fg = lane >> 4;                // MFMA role: query head fq, k group fg
+    const int fq = lane & 15, fg = lane >> 4;                // MFMA role: query head qt*16 + fq of the group, k group fg
     const int dch = lane % CPR, ksub = lane / CPR;           // row role: 16-byte chunk dch of key row ksub (+ i*KPI)
-    const bool row_ok = fq < p.group;
-    const int head = kvh * p.group + (row_ok ? fq : 0);
+    const bool row_ok = qt * 16 + fq < p.group;
+    const int head = kvh * p.group + (row_ok ? qt * 16 + fq : 0);
     char* vimg = smem + wave * TILE_BYTES;
     bf16x8 qf[KS];
     const int n_kt = pos0 / 64 + 1;
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
             }
         }
     }
-    if (FUSED && blockIdx.z == 0) {
+    if (FUSED && blockIdx.z == 0 && qt == 0) {
         // append the new key/value to the slabs for the following steps — after every load of this step (which used
         // the register copies), so the loads above are not ordered behind these stores
         int nblk, nrow;
@@ -625,7 +627,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
         }
     }
     if (gridDim.z > 1) {
-        float* rec = p.part + ((int64_t)(seq * p.nKV + kvh) * gridDim.z + blockIdx.z) * attn_part_floats<HD>();
+        const int pair = seq * gridDim.x + blockIdx.x;               // (sequence, kv head, query tile)
+        float* rec = p.part + ((int64_t)pair * gridDim.z + blockIdx.z) * attn_part_floats<HD>();
 #pragma unroll
         for (int d = 0; d < DT; d++) ((f32x4*)rec)[d * 64 + lane] = O[d];
         if (fg == 0) { rec[DT * 256 + fq] = mstar; rec[DT * 256 + 16 + fq] = L; }
@@ -634,12 +637,12 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
         // ticket, and if it is the last one acquire the others' records.  The order of the sum is z order regardless.
         __threadfence();
         int ticket = 0;
-        int32_t* cnt = p.part_cnt + seq * p.nKV + kvh;
+        int32_t* cnt = p.part_cnt + pair;
         if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         if (ticket != (int)gridDim.z - 1) return;
         __threadfence();
-        attn_decode_merge<HD>(p, seq, kvh, gridDim.z, lane);
+        attn_decode_merge<HD>(p, pair, tok, head, gridDim.z, lane);
         if (lane == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // for the next launch
         return;
     }

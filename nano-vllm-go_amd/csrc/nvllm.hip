@@ -749,7 +749,7 @@ extern "C" int nvl_finalize(nvl_model* m) {
     m->qkv = dmalloc<float>(Mmax * m->n_qkv);
     m->q = dmalloc_bytes(Mmax * qw * (int64_t)m->wsize);
     m->attn_out = dmalloc_bytes(Mp * qw * (int64_t)m->wsize);
-    if (!m->f32 && m->group <= 16 && (m->hd == 64 || m->hd == 128)) {     // partial results of a split decode attention (attn.h)
+    if (!m->f32 && (m->hd == 64 || m->hd == 128)) {     // partial results of a split decode attention (attn.h)
         m->attn_part = dmalloc<float>((int64_t)ATTN_SPLIT_MAX_PAIRS * ATTN_SPLIT_MAX * (m->hd == 64 ? attn_part_floats<64>() : attn_part_floats<128>()));
         m->attn_part_cnt = dmalloc<int32_t>(ATTN_SPLIT_MAX_PAIRS);
         NVL_HIP(hipMemset(m->attn_part_cnt, 0, ATTN_SPLIT_MAX_PAIRS * sizeof(int32_t)));
@@ -1050,7 +1050,7 @@ static int g_attn_split = 1;   // nvl_set_tuning key 25: split a decode attentio
 int decode_attn_cfg(const nvl_model* m, int n_seqs) {
     const int n_kt = m->ctx_hint > 0 ? (m->ctx_hint - 1) / 64 + 1 : 1 << 20;
     const int per_wave = m->hd == 64 ? 2 : 1;
-    const int wgs = m->nKV * n_seqs;
+    const int wgs = m->nKV * cdiv(m->group, 16) * n_seqs;
     if (g_attn_split && !g_attn_nw && m->attn_part && m->ctx_hint > 0 && wgs <= ATTN_SPLIT_MAX_PAIRS && n_kt >= 16) {
         const int want = cdiv(n_kt, 2 * per_wave);                       // workgroups of 2 waves that get a full round each
         const int ns = (wgs > 16 && n_kt < 32) ? 1 : std::min(std::min(want, ATTN_SPLIT_MAX), 128 / wgs);
@@ -1077,9 +1077,9 @@ void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, do
     if (m->f32) {
         const size_t lds = (size_t)m->Tmax * 4;
         hipLaunchKernelGGL(attn_f32_kernel, dim3(max_len, m->nH, n_seqs), dim3(256), lds, m->stream, a, m->hd);
-    } else if (max_len == 1 && m->group <= 16) {
+    } else if (max_len == 1) {
         const int cfg = decode_attn_cfg(m, n_seqs), nsplit = cfg >> 8;
-        dim3 grid(m->nKV, n_seqs, nsplit);
+        dim3 grid(m->nKV * cdiv(m->group, 16), n_seqs, nsplit);      // (kv head x 16-head query tile, sequence, key split)
         a.part = m->attn_part; a.part_cnt = m->attn_part_cnt;
         // waves per workgroup: each wave takes NT2 key tiles per round trip (2 for hd 64, 1 for hd 128).  Short contexts
         // need fewer than 8 waves (idle waves still cost LDS and a slot in the final merge), and once the grid alone
@@ -1515,7 +1515,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
 
     // decode, RMSNorm + SwiGLU, sequential block: every residual projection carries the norm that follows it (deferred
     // RMSNorm, gemm.h), so a step keeps ONE norm launch (layer 0's, after the embedding) instead of 2L + 1
-    const bool big_decode = max_len == 1 && M <= g_chunk_max_m && m->group <= 16 && g_force_tile == 0;
+    const bool big_decode = max_len == 1 && M <= g_chunk_max_m && g_force_tile == 0;
     const bool defer_ok = g_defer_norm && !m->f32 && (M <= 64 || (M <= DEFER_MAX_M && big_decode && g_defer_norm == 1)) && !c.use_moe && m->tp == 1 && !m->tp_force && !m->keep_hidden &&
                           c.block_style == NVL_BLOCK_SEQUENTIAL && c.norm_type == NVL_NORM_RMS &&
                           c.activation_type == NVL_ACT_SWIGLU && H % 256 == 0 && m->rs_part && m->n_mamba == 0;
@@ -1599,7 +1599,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
             if (qkv_deferred) set_deferred_in(m, aq);
             m->site = KS_QKV;
             gemm(m, EPI_STORE, true, aq);
-            fused_dec = !m->f32 && max_len == 1 && m->group <= 16;     // decode: RoPE + KV append live in the attention kernel
+            fused_dec = !m->f32 && max_len == 1;     // decode: RoPE + KV append live in the attention kernel
             if (!fused_dec) rope_kv(m, li, md, M);
         }
         attention(m, li, md, n_seqs, max_len, attn_flops, fused_dec);

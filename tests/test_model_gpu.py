@@ -406,3 +406,37 @@ def test_long_context_decode_splits_keys_over_workgroups(gpu, oracle, family, hd
             differs |= not np.array_equal(logits[1][s][i], logits[0][s][i])
     assert differs          # (the split launch sums in another order: identical bits would mean it never ran)
     hm.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_mqa_decode_with_more_than_16_query_heads(gpu, oracle, precision):
+    """MQA with 18 query heads on one KV head (Falcon-7B has 71): the decode attention kernel takes the group as query
+    tiles of 16 heads, two workgroups per (sequence, kv head) here, the second with 2 real heads; RoPE and the KV append
+    are done once, by the first.  Prefill, stepwise decode with teacher forcing, and the fused greedy loop."""
+    cfg, om, hm = build(gpu, oracle, "falcon", precision, num_heads=18, hidden=18 * 64, ffn_dim=2 * 18 * 64)
+    r = np.random.default_rng(41)
+    prompts = [r.integers(0, cfg["vocab_size"], n).tolist() for n in (70, 9)]
+    forced = [r.integers(0, cfg["vocab_size"], 5).tolist() for _ in prompts]
+    ids = [0, 1]
+    kvs = [om.new_cache() for _ in ids]
+    for i in ids:
+        hm.seq_reset(i)
+        om.forward_with_cache(prompts[i], kvs[i], 0)
+    hm.forward_batch(ids, prompts, [0, 0], want_logits=False)
+    for s in range(5):
+        lg, _ = hm.forward_batch(ids, [[forced[i][s]] for i in ids], [len(prompts[i]) + s for i in ids])
+        for i in ids:
+            want = om.forward_with_cache([forced[i][s]], kvs[i], len(prompts[i]) + s)[-1]
+            assert rel_err(lg[i], want) <= TOL[precision], (s, i)
+    # fused greedy loop == stepwise
+    for i in ids:
+        hm.seq_reset(i)
+    _, first = hm.forward_batch(ids, prompts, [0, 0], want_logits=False)
+    fused = hm.decode_greedy(ids, first, 4)
+    for i in ids:
+        hm.seq_reset(i)
+    _, cur = hm.forward_batch(ids, prompts, [0, 0], want_logits=False)
+    for s in range(4):
+        _, cur = hm.forward_batch(ids, [[int(t)] for t in cur], [len(prompts[i]) + s for i in ids], want_logits=False)
+        assert (fused[s] == cur).all()
+    hm.close()
