@@ -354,10 +354,19 @@ void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nt = p.K / G_BK;
+    // K split over gridDim.y workgroups per tile (residual projections of 65..512 rows: N / 128 x M / 128 tiles alone are
+    // far too few workgroups): slice y takes K tiles [kt0, kt0 + nt) and leaves an fp32 partial tile in sk_part[y]; the
+    // norm that follows sums the slices into x (PendingResid: the kernel boundary is the synchronisation)
+    const int nt_all = p.K / G_BK;
+    int nt = nt_all, kt0 = 0;
+    if (EPI == EPI_RESID && p.sk_part) {
+        const int per = nt_all / (int)gridDim.y, extra = nt_all - per * (int)gridDim.y;
+        kt0 = (int)blockIdx.y * per + ((int)blockIdx.y < extra ? (int)blockIdx.y : extra);
+        nt = per + ((int)blockIdx.y < extra ? 1 : 0);
+    }
 #pragma unroll
     for (int s = 0; s < STAGES - 1; s++)
-        if (s < nt) stage(s, s);
+        if (s < nt) stage(s, kt0 + s);
     wait_tiles_in_flight((nt < STAGES - 1 ? nt : STAGES - 1) - 1);
     __builtin_amdgcn_s_barrier();
     int cur = 0;
@@ -365,7 +374,7 @@ void gemm_bf16_kernel(GemmArgs p) {
         if (t + STAGES - 1 < nt) {
             int nb = cur + STAGES - 1;
             if (nb >= STAGES) nb -= STAGES;
-            stage(nb, t + STAGES - 1);
+            stage(nb, kt0 + t + STAGES - 1);
         }
         const char* sbuf = smem + cur * STAGE_BYTES;
 #pragma unroll
@@ -406,6 +415,13 @@ void gemm_bf16_kernel(GemmArgs p) {
                 const int f = (ntile >> 1) * 16 + 4 * fg;
                 epilogue_swiglu4<OutT>(p, m, f, acc[i][j], acc[i][j + 1]);
             }
+        } else if (EPI == EPI_RESID && p.sk_part) {
+            GemmArgs q = p;                                   // this slice's partial tile: plain fp32 store, bias with slice 0
+            q.C = p.sk_part + (int64_t)blockIdx.y * p.M * p.N; q.ldc = p.N; q.c_row0 = 0;
+            if (blockIdx.y != 0) q.bias = nullptr;
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                epilogue4<EPI_STORE, float>(q, m, n0 + wn * (TN * 16) + j * 16 + 4 * fg, acc[i][j]);
         } else {
 #pragma unroll
             for (int j = 0; j < TN; j++)
@@ -1078,8 +1094,8 @@ static inline void launch_gemm_tile(hipStream_t st, const GemmArgs& a) {
     constexpr int lds = gemm_lds_bytes<BM, BN, STAGES>();
     NVL_LDS_ATTR((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, OutT>), lds);
     const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, OutT>), dim3(tiles),
-                       dim3(WAVES_M * WAVES_N * 64), lds, st, a);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, OutT>),
+                       dim3(tiles, (EPI == EPI_RESID && a.sk_part) ? a.sk_slices : 1), dim3(WAVES_M * WAVES_N * 64), lds, st, a);
 }
 
 // how well `tiles` workgroups (one per CU at a time for the big tiles) fill 256 CUs

@@ -136,6 +136,7 @@ struct nvl_model {
     float* rs_part = nullptr;    // deferred RMSNorm: [H/16][64] partial sums of x^2 (gemm.h)
     int ctx_hint = 0;    // longest context (keys) of the batch being enqueued; 0 = unknown (decode attention sizing)
     float* sk_part = nullptr; int sk_max_slices = 4; int pending_slices = 0, pending_rows = 0; float pending_alpha = 1.f; const float* pending_part = nullptr;
+    int sk_rows = 64;             // rows the sk_part slices are allocated for
     const int32_t* pending_slot_of = nullptr; const float* pending_gate_w = nullptr;   // MoE combine folded into the next norm
     // per-call metadata (one pinned host block mirrored on the device)
     int32_t* meta_host = nullptr; int32_t* meta_dev = nullptr; int64_t meta_ints = 0;

@@ -18,6 +18,8 @@ using namespace nvl;
 
 static thread_local std::string g_create_err;
 constexpr int ATTN_SPLIT_MAX_PAIRS = 32, ATTN_SPLIT_MAX = 8;     // split decode attention: (sequence, kv head) pairs a launch may have; most workgroups per pair
+constexpr int SK_TILE_MAX_M = 512, SK_TILE_MAX_SLICES = 8;      // split-K of the tile kernel for mid-size residual projections (resid_gemm)
+static int g_sk_tile = 1;            // nvl_set_tuning key 26: that split (0 = off)
 constexpr int MOE_DOWN_SLICES = 4;    // at most this many K slices (workgroups per column tile) in the dense-masked MoE down projection
 static inline int moe_down_slices(int E) { int s = MOE_DOWN_SLICES; while (s > 1 && E % s) s--; return s; }   // a whole number of experts per slice
 
@@ -799,7 +801,9 @@ extern "C" int nvl_finalize(nvl_model* m) {
         m->myn = dmalloc_bytes(Mp * m->mEH * (int64_t)m->wsize);
         NVL_HIP(hipMemsetAsync(m->myn, 0, (size_t)(Mp * m->mEH) * m->wsize, m->stream));
     }
-    if (!m->f32) m->sk_part = dmalloc<float>((int64_t)m->sk_max_slices * 64 * H);
+    // split-K partial slices of the residual projections: decode (<= 64 rows) and mid-size batches (<= SK_TILE_MAX_M rows)
+    m->sk_rows = (int)std::min<int64_t>(std::max<int64_t>(Mmax, 64), SK_TILE_MAX_M);
+    if (!m->f32) m->sk_part = dmalloc<float>((int64_t)std::max(m->sk_max_slices, SK_TILE_MAX_SLICES) * m->sk_rows * H);
     if (!m->f32) m->rs_part = dmalloc<float>((int64_t)cdiv(H, 16) * DEFER_MAX_M);
     if (m->tp > 1 || m->tp_force) m->tp_part = dmalloc<float>(Mmax * H);
     m->meta_ints = 3 * Mmax + 5 * S + m->table_cap + 16;
@@ -1280,6 +1284,15 @@ void resid_gemm(nvl_model* m, const void* A, int lda, const void* W, const float
         const int nblocks = N / 16;
         if (g_sk_slices > 0) slices = g_sk_slices;
         else while (slices < m->sk_max_slices && nblocks * slices < 256 && (K >> 5) / (slices * 2) >= 8) slices *= 2;
+    }
+    // 65..512 rows (a short prompt, a few hundred decode rows that do not take the decode form): N / 128 x M / 128 tiles of the
+    // lock-step kernel are a handful of workgroups (FFN-down of Llama-1B at 512 rows: 64), and the 64-row groups of the decode
+    // form pull every activation row through every CU (1.3 GB of ingest for that projection: 85 us).  K split over
+    // gridDim.y workgroups per tile instead, the slices summed by the norm that follows (which must be the row kernel).
+    if (g_sk_tile && !m->f32 && M > 64 && M <= m->sk_rows && M <= 512 && !m->keep_hidden && m->sk_part && m->pending_slices == 0 &&
+        N % 128 == 0 && K % 64 == 0 && m->H <= 1024 * NORM_ROW_MAXCH && N == m->H && g_force_tile == 0 && m->n_mamba == 0) {
+        const int tiles = cdiv(M, 128) * (N / 128);
+        while (slices < SK_TILE_MAX_SLICES && tiles * slices < 512 && K / (slices * 2) >= 512) slices *= 2;
     }
     if (slices > 1) {
         a.sk_part = m->sk_part; a.sk_slices = slices;

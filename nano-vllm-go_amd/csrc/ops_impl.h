@@ -396,6 +396,7 @@ extern "C" int nvl_set_tuning(int key, int value) {
     g_tune_epoch++;        // captured decode graphs bake the tuning in: a new epoch makes them miss
     if (key == 21) { const int old = g_use_graphs; g_use_graphs = value; return old; }
     if (key == 22) { const int old = g_moe_dense; g_moe_dense = value; return old; }
+    if (key == 26) { const int old = g_sk_tile; g_sk_tile = value; return old; }
     if (key == 25) { const int old = g_attn_split; g_attn_split = value; return old; }
     if (key == 24) { const int old = g_x_mask; g_x_mask = value; return old; }
     if (key == 23) { const int old = g_p2p_oneshot_rows; g_p2p_oneshot_rows = value; return old; }
