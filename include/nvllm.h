@@ -409,7 +409,7 @@ int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int 
  * stream) the tensor-parallel P2P all-reduce sends one-shot; above it reduce-scatter + all-gather (default 64).
  * key 25: a decode attention over >= 1024 keys in a tiny batch (<= 32 (sequence, kv head) pairs: Llama B <= 4) deals its key
  * tiles over up to 8 workgroups per pair (<= 128 in all), the last of which combines the partial results (1, default; 0 = never).
- * key 26: residual projections of 65..512 rows split K over up to 8 workgroups per 128x128 tile, the slices summed by the
+ * key 26: residual projections of 65..2048 rows split K over up to 8 workgroups per 128x128 tile, the slices summed by the
  * norm that follows (1, default; 0 = the 64-row groups of the decode form / plain tiles).
  * key 24: the decode GEMM kernels do not fetch the activation rows >= M of a padded 16-row tile (1, default).
  * The settings are PROCESS-GLOBAL and unsynchronised (every model in the process sees them): set them from one thread

@@ -118,10 +118,10 @@ struct PendingResid {
 // normalises one row held in registers (same arithmetic as norm_kernel) into LDS; the workgroup then writes the tile's
 // 1-KiB operand blocks with full-line stores (norm_kernel's lanes each write 8 bytes of a block: 16-byte fragments at a
 // 256-byte stride).  H <= 64 * 4 * MAXCH (instances for 8 and 16 chunks per lane: H <= 2048 / 4096).
-template <int MAXCH>
-__global__ __launch_bounds__(1024) void norm_tile16_kernel(const float* __restrict__ x, const int32_t* __restrict__ rows_idx,
+template <int MAXCH, bool PENDING = false>
+__global__ __launch_bounds__(1024) void norm_tile16_kernel(float* __restrict__ x, const int32_t* __restrict__ rows_idx,
                                                            const float* __restrict__ w, const float* __restrict__ b,
-                                                           float eps, bf16_t* __restrict__ y, int rows, int H) {
+                                                           float eps, bf16_t* __restrict__ y, int rows, int H, PendingResid pr) {
     extern __shared__ __attribute__((aligned(16))) char smem_n[];
     bf16_t* tile = (bf16_t*)smem_n;                       // [16][H]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -129,12 +129,37 @@ __global__ __launch_bounds__(1024) void norm_tile16_kernel(const float* __restri
     const int H4 = H >> 2;
     if (r < rows) {
         const int src = rows_idx ? rows_idx[r] : r;
-        const float* xr = x + (int64_t)src * H;
+        float* xr = x + (int64_t)src * H;
         f32x4 v[MAXCH];
 #pragma unroll
         for (int c = 0; c < MAXCH; c++) {
             const int j = lane + c * 64;
             v[c] = j < H4 ? *(const f32x4*)(xr + j * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (PENDING) {     // complete the residual add a split-K projection left as slices (plain slices only: no MoE gather here)
+            // slice loop outside, chunks unrolled inside, eight chunks at a time: the row and the running sums stay in registers
+#pragma unroll
+            for (int c0 = 0; c0 < MAXCH; c0 += 8) {
+                f32x4 sl[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) sl[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < pr.slices; k++) {
+                    const float* ps = pr.part + ((int64_t)k * pr.rows_total + src) * H;
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const int j = lane + (c0 + c) * 64;
+                        if (j < H4) sl[c] += *(const f32x4*)(ps + j * 4);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const int j = lane + (c0 + c) * 64;
+                    if (j < H4) {
+                        v[c0 + c] += pr.alpha * sl[c];      // (slices in order, then alpha: as norm_row_kernel)
+                        *(f32x4*)(xr + j * 4) = v[c0 + c];
+                    }
+                }
+            }
         }
         float mean = 0.f, inv;
         if (b == nullptr) {

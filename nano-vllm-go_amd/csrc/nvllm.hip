@@ -18,7 +18,7 @@ using namespace nvl;
 
 static thread_local std::string g_create_err;
 constexpr int ATTN_SPLIT_MAX_PAIRS = 32, ATTN_SPLIT_MAX = 8;     // split decode attention: (sequence, kv head) pairs a launch may have; most workgroups per pair
-constexpr int SK_TILE_MAX_M = 512, SK_TILE_MAX_SLICES = 8;      // split-K of the tile kernel for mid-size residual projections (resid_gemm)
+constexpr int SK_TILE_MAX_M = 2048, SK_TILE_MAX_SLICES = 8;      // split-K of the tile kernel for mid-size residual projections (resid_gemm)
 static int g_sk_tile = 1;            // nvl_set_tuning key 26: that split (0 = off)
 constexpr int MOE_DOWN_SLICES = 4;    // at most this many K slices (workgroups per column tile) in the dense-masked MoE down projection
 static inline int moe_down_slices(int E) { int s = MOE_DOWN_SLICES; while (s > 1 && E % s) s--; return s; }   // a whole number of experts per slice
@@ -1011,20 +1011,23 @@ void launch_norm(nvl_model* m, float* x, const int32_t* rows_idx, const float* w
         pr.part = m->pending_part; pr.slices = m->pending_slices; pr.rows_total = m->pending_rows; pr.alpha = m->pending_alpha;
         pr.slot_of = m->pending_slot_of; pr.gate_w = m->pending_gate_w;
         m->pending_slices = 0; m->pending_slot_of = nullptr; m->pending_gate_w = nullptr;
-        if (!(rows <= 512 && m->H <= 1024 * NORM_ROW_MAXCH)) throw std::runtime_error("norm: pending residual needs the row kernel");
+        const bool row_kernel = rows <= 512 && m->H <= 1024 * NORM_ROW_MAXCH;
+        const bool tile_kernel = sizeof(ActT) == 2 && m->H % 32 == 0 && m->H <= 2048 && g_norm_t16 && !pr.slot_of;   // (the 16-chunk instance would spill)
+        if (!row_kernel && !tile_kernel) throw std::runtime_error("norm: no kernel for this pending residual");
     }
     if (rows <= 512 && m->H <= 1024 * NORM_ROW_MAXCH)
         hipLaunchKernelGGL((norm_row_kernel<ActT>), dim3(rows), dim3(256), 0, m->stream, x, rows_idx, w, b,
                            m->cfg.norm_eps, (ActT*)y, m->H, pr);
     else if (sizeof(ActT) == 2 && m->H % 32 == 0 && m->H <= 4096 && g_norm_t16) {   // (wider rows would spill: norm_kernel)
         // 16 rows x H bf16 of LDS (up to 160 KiB); the row sits in registers: instance by chunks per lane
-#define NVL_NT16(CH)                                                                                                   \
+#define NVL_NT16(CH, PEND)                                                                                             \
         do {                                                                                                           \
-            NVL_LDS_ATTR(norm_tile16_kernel<CH>, 160 * 1024);                                                          \
-            hipLaunchKernelGGL(norm_tile16_kernel<CH>, dim3(cdiv(rows, 16)), dim3(1024), (size_t)16 * m->H * 2, m->stream, x, \
-                               rows_idx, w, b, m->cfg.norm_eps, (bf16_t*)y, rows, m->H);                                \
+            NVL_LDS_ATTR((norm_tile16_kernel<CH, PEND>), 160 * 1024);                                                  \
+            hipLaunchKernelGGL((norm_tile16_kernel<CH, PEND>), dim3(cdiv(rows, 16)), dim3(1024), (size_t)16 * m->H * 2, m->stream, x, \
+                               rows_idx, w, b, m->cfg.norm_eps, (bf16_t*)y, rows, m->H, pr);                            \
         } while (0)
-        if (m->H <= 2048) NVL_NT16(8); else NVL_NT16(16);
+        if (pr.part) NVL_NT16(8, true);        // (H <= 2048: checked above)
+        else { if (m->H <= 2048) NVL_NT16(8, false); else NVL_NT16(16, false); }
 #undef NVL_NT16
     } else
         hipLaunchKernelGGL((norm_kernel<ActT>), dim3(cdiv(rows, 4)), dim3(256), 0, m->stream, x, rows_idx, w, b,
@@ -1289,8 +1292,9 @@ void resid_gemm(nvl_model* m, const void* A, int lda, const void* W, const float
     // lock-step kernel are a handful of workgroups (FFN-down of Llama-1B at 512 rows: 64), and the 64-row groups of the decode
     // form pull every activation row through every CU (1.3 GB of ingest for that projection: 85 us).  K split over
     // gridDim.y workgroups per tile instead, the slices summed by the norm that follows (which must be the row kernel).
-    if (g_sk_tile && !m->f32 && M > 64 && M <= m->sk_rows && M <= 512 && !m->keep_hidden && m->sk_part && m->pending_slices == 0 &&
-        N % 128 == 0 && K % 64 == 0 && m->H <= 1024 * NORM_ROW_MAXCH && N == m->H && g_force_tile == 0 && m->n_mamba == 0) {
+    const bool norm_ok = (M <= 512 && m->H <= 1024 * NORM_ROW_MAXCH) || (m->H % 32 == 0 && m->H <= 2048 && g_norm_t16);   // launch_norm
+    if (g_sk_tile && !m->f32 && M > 64 && M <= m->sk_rows && !m->keep_hidden && m->sk_part && m->pending_slices == 0 &&
+        N % 128 == 0 && K % 64 == 0 && norm_ok && N == m->H && g_force_tile == 0 && m->n_mamba == 0) {
         const int tiles = cdiv(M, 128) * (N / 128);
         while (slices < SK_TILE_MAX_SLICES && tiles * slices < 512 && K / (slices * 2) >= 512) slices *= 2;
     }
