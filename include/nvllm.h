@@ -251,7 +251,10 @@ int nvl_decode_greedy(nvl_model* m, int n_seqs, const int64_t* seq_ids, const in
                       int32_t* out_tokens);
 
 /* Debug/parity: copy the residual stream after layer `layer` of the LAST nvl_forward call,
- * [sum(seq_lens), H] fp32 (requires nvl_set_debug(m, 1) before the call). */
+ * [sum(seq_lens), H] fp32 (requires nvl_set_debug(m, 1 or 2) before the call).  Mode 1 completes every residual add in its
+ * own launch (no split-K partials left to the next norm, no deferred RMSNorm, no graph replay): the layer outputs of a
+ * simplified kernel sequence.  Mode 2 records the same values BESIDE the unmodified product path — kernel selection is
+ * exactly what an untapped call runs; adds still pending for the next norm are included in the copy only. */
 int nvl_set_debug(nvl_model* m, int keep_hidden);
 int nvl_get_hidden(nvl_model* m, int layer, float* out, int64_t n_floats);
 /* Debug/parity: copy a sequence's cache for one layer as the reference lays it out,
@@ -260,6 +263,13 @@ int nvl_get_kv(nvl_model* m, int64_t seq_id, int layer, float* k_out, float* v_o
 /* Mamba2Layer.SSMState of a sequence's slot for a Mamba2 layer, [heads, head_dim, state] fp32 (mamba2.go:29-30; per
  * SEQUENCE here, per layer in the reference).  Returns the number of floats, or < 0. */
 int nvl_get_mamba_state(nvl_model* m, int64_t seq_id, int layer, float* out);
+/* Debug/parity: read a 2-D weight back from the device as the reference holds it after loading ([in, out] fp32,
+ * generic_loader.go:398-403) — whatever layout the kernels keep it in.  kind = NVL_T_*; out is [in_features][out_features].
+ * Available between the upload and nvl_finalize for the projections finalize fuses (Q, K, V, KV, W1, MoE-in), at any
+ * time for the others; a tensor-parallel rank returns its own slice.  Returns 0, or NVL_ERR_STATE when the tensor is gone.
+ * This is how the reference's own fixture for this path (purego/tensor/falcon_split_test.go:7-158: the fused Falcon QKV
+ * split) is replayed against nvl_upload_falcon_qkv itself (tests/test_loader_gpu.py). */
+int nvl_get_weight(nvl_model* m, int kind, int layer, float* out, int64_t in_features, int64_t out_features);
 
 /* ---- runner: ModelRunner.Run semantics (nanovllm/model_runner.go:9-16) ---- */
 /* Replaces TensorModelRunner.Run (tensor_model_runner.go:55-97) for a scheduler batch:

@@ -300,6 +300,28 @@ __global__ __launch_bounds__(256) void norm_row_kernel(float* __restrict__ x,
     norm_row_finish<ActT>(v, ww, bb, b, eps, y, r, H, red);
 }
 
+// Debug tap (nvl_set_debug mode 2): the residual stream after a layer as the NEXT kernel will see it — x plus whatever a
+// split-K / MoE projection left pending for the following norm (same arithmetic and order as norm_row_kernel) — copied
+// out WITHOUT touching x or the pending state, so the product path runs exactly as it does untapped.
+__global__ __launch_bounds__(256) void tap_hidden_kernel(const float* __restrict__ x, float* __restrict__ dst, int H, PendingResid pr) {
+    const int r = blockIdx.x;
+    const float* xr = x + (int64_t)r * H;
+    for (int j = threadIdx.x; j < (H >> 2); j += 256) {
+        f32x4 v = *(const f32x4*)(xr + j * 4);
+        if (pr.part && pr.slot_of) {
+            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < pr.slices; k++)
+                s += pr.gate_w[(int64_t)r * pr.slices + k] * *(const f32x4*)(pr.part + (int64_t)pr.slot_of[(int64_t)r * pr.slices + k] * H + j * 4);
+            v = v + (pr.alpha != 0.f ? pr.alpha * s : s);
+        } else if (pr.part) {
+            f32x4 s = *(const f32x4*)(pr.part + (int64_t)r * H + j * 4);
+            for (int k = 1; k < pr.slices; k++) s += *(const f32x4*)(pr.part + ((int64_t)k * pr.rows_total + r) * H + j * 4);
+            v += pr.alpha * s;
+        }
+        *(f32x4*)(dst + (int64_t)r * H + j * 4) = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // RoPE (rope.go:153-205) on Q and K as they leave the fused QKV GEMM, plus the KV append that
 // replaces Concatenate (tensor.go:283-321): K -> slab[pos][hd], V -> slab[pos][hd] (VT = true would write V^T: unused).

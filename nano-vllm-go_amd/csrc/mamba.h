@@ -38,6 +38,14 @@ struct MambaArgs {
     const int32_t* seq_len;
     const int32_t* seq_pos;        // first position of the sequence in this call
     const int32_t* seq_slot;       // KV slot of the sequence (blk_table in slab mode)
+    // A history longer than max_batch_tokens is prefilled in chunks by the runner (nvllm.hip runner_impl); the reference
+    // runs it as ONE Forward whose convolution window spans the whole history.  For those chunks only, the raw xBC rows of
+    // the last K-1 tokens of the previous chunk are kept per (slot, Mamba2 layer) and stand in for the zero padding:
+    // chain 0 = off (every other call: the reference's zero padding), 1 = first chunk (save the tail), 2 = later chunk
+    // (use the saved tail, then save the new one).
+    float* tail;                   // this layer's tails: slot s at tail + s * tail_slot_stride, [K-1][conv_dim]
+    int64_t tail_slot_stride;
+    int chain;
 };
 
 __device__ __forceinline__ float silu_ref(float x) { return x / (1.0f + __expf(-x)); }
@@ -53,6 +61,9 @@ __global__ __launch_bounds__(256) void mamba_conv_kernel(MambaArgs p) {
         for (int k = 0; k < p.K; k++) {                         // out[t] = sum_k x[t - (K-1) + k] * w[c][k], zero before the call
             const int back = p.K - 1 - k;
             if (back <= j) sum = fmaf(row[c - (int64_t)back * p.P], p.conv_w[(int64_t)c * p.K + k], sum);
+            else if (p.chain == 2)     // continued chunk: the window reaches into the previous chunk's last K-1 tokens
+                sum = fmaf(p.tail[(int64_t)p.seq_slot[p.tok_seq[t]] * p.tail_slot_stride + (int64_t)(p.K - 1 - (back - j)) * p.conv_dim + c],
+                           p.conv_w[(int64_t)c * p.K + k], sum);
         }
         if (p.conv_b) sum += p.conv_b[c];
         p.xbc[(int64_t)t * p.conv_dim + c] = silu_ref(sum);
@@ -61,6 +72,24 @@ __global__ __launch_bounds__(256) void mamba_conv_kernel(MambaArgs p) {
         float v = p.proj[(int64_t)t * p.P + p.EH + p.conv_dim + h];
         if (p.dt_bias) v += p.dt_bias[h];
         p.delta[(int64_t)t * p.nh + h] = softplus_ref(v);
+    }
+}
+
+// grid (sequences), 256 threads over channels: after the convolution of a chunk of a chained prefill (chain >= 1), keep the
+// raw xBC rows of the sequence's last K-1 tokens for the next chunk (a chunk shorter than K-1 keeps the newest old rows).
+__global__ __launch_bounds__(256) void mamba_tail_kernel(MambaArgs p) {
+    const int seq = blockIdx.x;
+    const int t0 = p.seq_tok_start[seq], n = p.seq_len[seq];
+    float* tl = p.tail + (int64_t)p.seq_slot[seq] * p.tail_slot_stride;
+    const bool have_old = p.chain == 2 && p.seq_pos[seq] > 0;
+    for (int c = threadIdx.x; c < p.conv_dim; c += blockDim.x) {
+        float old[8], nw[8];
+        for (int i = 0; i < p.K - 1; i++) old[i] = have_old ? tl[(int64_t)i * p.conv_dim + c] : 0.f;
+        for (int i = 0; i < p.K - 1; i++) {
+            const int rel = n - (p.K - 1) + i;              // token of this call that lands in tail row i
+            nw[i] = rel >= 0 ? p.proj[(int64_t)(t0 + rel) * p.P + p.EH + c] : old[i + n];
+        }
+        for (int i = 0; i < p.K - 1; i++) tl[(int64_t)i * p.conv_dim + c] = nw[i];
     }
 }
 

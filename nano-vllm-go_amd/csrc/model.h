@@ -144,6 +144,8 @@ struct nvl_model {
     int n_mamba = 0, mEH = 0, mConv = 0, mP = 0, m_nh = 0, m_hd = 0, m_ss = 0, m_ng = 0, m_K = 0;
     float* ssm_state = nullptr; int64_t ssm_layer_stride = 0, ssm_slot_stride = 0;
     float *mproj = nullptr, *mxbc = nullptr, *mdelta = nullptr, *my = nullptr; void* myn = nullptr;
+    float* conv_tail = nullptr; int64_t conv_tail_layer_stride = 0, conv_tail_slot_stride = 0;   // chunked prefill only (mamba.h MambaArgs::chain)
+    int conv_chain = 0;          // set by runner_impl around the chunks of one long history
     SampleBufs samp;             // nvl_sample scratch
     int32_t* samp_hist = nullptr; int32_t* samp_hist_len = nullptr; int64_t samp_hist_cap = 0;   // nvl_decode_sampled: device-kept histories
     float* samp_u_steps = nullptr; int64_t samp_u_cap = 0;
@@ -153,9 +155,11 @@ struct nvl_model {
     // hipGraph replay of decode passes (one graph per launch configuration; first sight eager, second captured, then replayed)
     std::map<std::array<int, 5>, hipGraphExec_t> graphs;
     std::set<std::array<int, 5>> graph_seen;
+    std::vector<hipGraphExec_t> graphs_retired;       // evicted execs, destroyed after the next stream sync (reap_graphs)
     bool graphs_ok = true;
     int32_t* am_host = nullptr;                       // pinned: argmax ids of a replayed decode pass
     // debug
+    bool tap = false;            // nvl_set_debug mode 2: record every layer's residual stream without leaving the product path
     bool keep_hidden = false; float* hidden = nullptr; int64_t hidden_tokens = 0; int hidden_last_M = 0;
     // stats
     nvl_stats stats{};

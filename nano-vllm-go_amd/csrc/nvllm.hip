@@ -68,10 +68,23 @@ void* dmalloc_bytes(int64_t n) {
     return p;
 }
 void dfree(void* p) { if (p) (void)hipFree(p); }
-void clear_graphs(nvl_model* m) {      // captured decode passes (replay_or_capture)
-    for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+// Captured decode passes (replay_or_capture).  A graph exec may still be executing on the stream (the fused decode loop
+// enqueues its steps without a host sync), so nothing is destroyed while work can be in flight: retire_graphs() only moves
+// the execs aside, reap_graphs() destroys them and is called right after a hipStreamSynchronize of the model's stream.
+void reap_graphs(nvl_model* m) {
+    for (auto ge : m->graphs_retired) (void)hipGraphExecDestroy(ge);
+    m->graphs_retired.clear();
+}
+void retire_graphs(nvl_model* m) {
+    for (auto& kv : m->graphs) m->graphs_retired.push_back(kv.second);
     m->graphs.clear();
     m->graph_seen.clear();
+}
+// every captured pass bakes in the addresses of the buffers it was captured with: call before any of them is re-allocated
+void clear_graphs(nvl_model* m) {
+    retire_graphs(m);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    reap_graphs(m);
 }
 void free_sample_bufs(SampleBufs& b) {
     dfree(b.work); dfree(b.cnt); dfree(b.hist); dfree(b.off); dfree(b.out); dfree(b.u); dfree(b.probs);
@@ -316,6 +329,7 @@ extern "C" void nvl_destroy(nvl_model* m) {
     clear_graphs(m);
     if (m->am_host) (void)hipHostFree(m->am_host);
     dfree(m->ring_pos0);
+    dfree(m->conv_tail);
     dfree(m->ssm_state); dfree(m->mproj); dfree(m->mxbc); dfree(m->mdelta); dfree(m->my); dfree(m->myn);
     free_sample_bufs(m->samp);
     dfree(m->samp_hist); dfree(m->samp_hist_len); dfree(m->samp_u_steps);
@@ -794,6 +808,12 @@ extern "C" int nvl_finalize(nvl_model* m) {
         m->ssm_slot_stride = m->ssm_layer_stride * m->n_mamba;
         m->ssm_state = dmalloc<float>(m->ssm_slot_stride * S);
         NVL_HIP(hipMemsetAsync(m->ssm_state, 0, (size_t)(m->ssm_slot_stride * S) * 4, m->stream));
+        if (m->m_K > 1) {     // raw xBC rows of a chunked prefill's last K-1 tokens, per (slot, Mamba2 layer)
+            m->conv_tail_layer_stride = (int64_t)(m->m_K - 1) * m->mConv;
+            m->conv_tail_slot_stride = m->conv_tail_layer_stride * m->n_mamba;
+            m->conv_tail = dmalloc<float>(m->conv_tail_slot_stride * S);
+            NVL_HIP(hipMemsetAsync(m->conv_tail, 0, (size_t)(m->conv_tail_slot_stride * S) * 4, m->stream));
+        }
         m->mproj = dmalloc<float>(Mmax * m->mP);
         m->mxbc = dmalloc<float>(Mmax * m->mConv);
         m->mdelta = dmalloc<float>(Mmax * m->m_nh);
@@ -1468,11 +1488,12 @@ namespace {
 // of a key runs eagerly (it also sets the per-function attributes, which must not happen during capture).
 template <typename F>
 bool replay_or_capture(nvl_model* m, const std::array<int, 5>& key, F&& enqueue) {
-    if (!g_use_graphs || !m->graphs_ok || m->profile || m->keep_hidden || m->tp > 1 || m->tp_force) return false;
+    if (!g_use_graphs || !m->graphs_ok || m->profile || m->keep_hidden || m->tap || m->tp > 1 || m->tp_force) return false;
     auto it = m->graphs.find(key);
     if (it != m->graphs.end()) { NVL_HIP(hipGraphLaunch(it->second, m->stream)); m->stats.graph_replays++; return true; }
     if (!m->graph_seen.count(key)) { m->graph_seen.insert(key); return false; }
-    if (m->graphs.size() >= 64) clear_graphs(m);         // (keys come and go with the context length: keep the table small)
+    if (m->graphs.size() >= 64) retire_graphs(m);        // (keys come and go with the context length: keep the table small;
+                                                         //  earlier steps' replays may still be running: destroyed at the next sync)
     if (hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); m->graphs_ok = false; return false; }
     hipGraph_t g = nullptr;
     try {
@@ -1495,6 +1516,17 @@ bool replay_or_capture(nvl_model* m, const std::array<int, 5>& key, F&& enqueue)
     return true;
 }
 
+// debug taps: the residual stream after layer li.  Mode 1 (keep_hidden) runs every residual add to completion in its own
+// launch, so x is the layer's output; mode 2 (tap) leaves the product path alone and adds what is still pending.
+void tap_layer(nvl_model* m, int li, int M) {
+    if (!m->keep_hidden && !m->tap) return;
+    float* dst = m->hidden + (int64_t)li * M * m->H;
+    if (m->pending_slices == 0) { NVL_HIP(hipMemcpyAsync(dst, m->x, (size_t)M * m->H * 4, hipMemcpyDeviceToDevice, m->stream)); return; }
+    PendingResid pr{m->pending_part, m->pending_slices, m->pending_rows, m->pending_alpha, m->pending_slot_of, m->pending_gate_w};
+    hipLaunchKernelGGL(tap_hidden_kernel, dim3(M), dim3(256), 0, m->stream, m->x, dst, m->H, pr);
+    NVL_HIP(hipGetLastError());
+}
+
 // Enqueue ONE forward pass (embedding ... argmax) on the model's stream for the batch described by the device
 // metadata `md` — no host synchronisation.  Returns the number of logits rows produced.
 // seam: 0 = whole pass; bit 0 = x and layer 0's normed operand are already in place (skip embed + first norm);
@@ -1506,7 +1538,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
     const int H = m->H;
     m->pending_slices = 0;
     m->phase = max_len > 1 ? 0 : 1;         // per-site profile: prefill / decode
-    if (m->keep_hidden && m->hidden_tokens < M) {
+    if ((m->keep_hidden || m->tap) && m->hidden_tokens < M) {
         dfree(m->hidden);
         m->hidden = dmalloc<float>((int64_t)m->L * M * H);
         m->hidden_tokens = M;
@@ -1559,9 +1591,13 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
             a.state = m->ssm_state + (int64_t)l.mamba_idx * m->ssm_layer_stride; a.state_slot_stride = m->ssm_slot_stride;
             a.tok_pos = md.tok_pos; a.tok_seq = md.tok_tbl; a.seq_tok_start = md.seq_tok_start; a.seq_len = md.seq_len;
             a.seq_pos = md.seq_pos; a.seq_slot = md.blk_table;     // slab mode: token -> sequence index i, blk_table[i] = slot
+            a.chain = m->conv_tail ? m->conv_chain : 0;
+            a.tail = m->conv_tail ? m->conv_tail + (int64_t)l.mamba_idx * m->conv_tail_layer_stride : nullptr;
+            a.tail_slot_stride = m->conv_tail_slot_stride;
             {
                 KScope ks(m, KC_OTHER, 0, KS_MAMBA_CONV, (double)M * (m->mP + m->mConv + m->m_nh) * 4.0);
                 hipLaunchKernelGGL(mamba_conv_kernel, dim3(M), dim3(256), 0, m->stream, a);
+                if (a.chain) hipLaunchKernelGGL(mamba_tail_kernel, dim3(n_seqs), dim3(256), 0, m->stream, a);
                 NVL_HIP(hipGetLastError());
             }
             {
@@ -1587,8 +1623,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
             ffn_up(m, l, M);
             m->site = KS_FFN_DOWN;
             resid_gemm(m, m->hbuf, m->F, l.t[NVL_T_W2].p, (const float*)l.t[NVL_T_B2].p, m->resid_alpha, M, H, m->F);
-            if (m->keep_hidden)
-                NVL_HIP(hipMemcpyAsync(m->hidden + (int64_t)li * M * H, m->x, (size_t)M * H * 4, hipMemcpyDeviceToDevice, m->stream));
+            tap_layer(m, li, M);
             continue;
         }
         const bool qkv_deferred = xn_deferred;
@@ -1656,8 +1691,7 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
                 xn_deferred = defer2;
             }
         }
-        if (m->keep_hidden)
-            NVL_HIP(hipMemcpyAsync(m->hidden + (int64_t)li * M * H, m->x, (size_t)M * H * 4, hipMemcpyDeviceToDevice, m->stream));
+        tap_layer(m, li, M);
     }
 
     // ---- final norm + LM head on the rows the caller keeps (generic_model.go:464-477, :595-604) ----
@@ -1798,6 +1832,7 @@ extern "C" int nvl_forward(nvl_model* m, int n_seqs, const int64_t* seq_ids, con
         NVL_HIP(hipMemcpy2DAsync(logits_out, (size_t)m->V * 4, m->logits, (size_t)m->Vpad * 4, (size_t)m->V * 4,
                                  (size_t)rows, hipMemcpyDeviceToHost, m->stream));
     NVL_HIP(hipStreamSynchronize(m->stream));
+    reap_graphs(m);
     p2p_check(m);
     m->last_rows = rows;
     if (argmax_out) {
@@ -1965,6 +2000,7 @@ void decode_loop(nvl_model* m, const Meta& hm, int n_seqs, int n_steps, int32_t*
     const int32_t* h_pos = hm.seq_pos;
     const Meta md = bind_meta(m, m->meta_dev, M);
     if ((int64_t)n_steps * n_seqs > m->ring_ints) {
+        clear_graphs(m);      // the fused loop's captured steps hold the old ring address as a kernel argument
         dfree(m->ring);
         m->ring_ints = (int64_t)n_steps * n_seqs;
         m->ring = dmalloc<int32_t>(m->ring_ints);
@@ -1972,8 +2008,8 @@ void decode_loop(nvl_model* m, const Meta& hm, int n_seqs, int n_steps, int32_t*
     NVL_HIP(hipEventRecord(m->ev0, m->stream));
     NVL_HIP(hipMemcpyAsync(m->meta_dev, m->meta_host, meta_bytes(m, M), hipMemcpyHostToDevice, m->stream));
     NVL_HIP(hipMemcpyAsync(m->ring_pos0, h_pos, (size_t)n_seqs * 4, hipMemcpyHostToDevice, m->stream));   // (pinned meta_host)
-    const bool dbg = m->keep_hidden;
-    m->keep_hidden = false;                      // the per-layer taps belong to single nvl_forward calls
+    const bool dbg = m->keep_hidden, dbg_tap = m->tap;
+    m->keep_hidden = false; m->tap = false;      // the per-layer taps belong to single nvl_forward calls
     for (int s = 0; s < n_steps; s++) {
         double attn_flops = 0, kv_tok = 0;
         for (int i = 0; i < n_seqs; i++) {
@@ -2024,10 +2060,11 @@ void decode_loop(nvl_model* m, const Meta& hm, int n_seqs, int n_steps, int32_t*
         }
         if (!replayed) one_step();
     }
-    m->keep_hidden = dbg;
+    m->keep_hidden = dbg; m->tap = dbg_tap;
     NVL_HIP(hipEventRecord(m->ev1, m->stream));
     NVL_HIP(hipMemcpyAsync(out_tokens, m->ring, (size_t)n_steps * n_seqs * 4, hipMemcpyDeviceToHost, m->stream));
     NVL_HIP(hipStreamSynchronize(m->stream));
+    reap_graphs(m);
     p2p_check(m);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, m->ev0, m->ev1);
@@ -2195,7 +2232,8 @@ extern "C" int nvl_decode_sampled(nvl_model* m, int n_seqs, const int64_t* seq_i
 // =================================================================================================
 extern "C" int nvl_set_debug(nvl_model* m, int keep_hidden) {
     if (!m) return NVL_ERR_INVALID;
-    m->keep_hidden = keep_hidden != 0;
+    m->keep_hidden = keep_hidden == 1;      // 1: per-layer residual stream, every residual add completed in its own launch
+    m->tap = keep_hidden == 2;              // 2: the same record taken beside the unmodified product path (pending adds included)
     return NVL_OK;
 }
 extern "C" int nvl_get_hidden(nvl_model* m, int layer, float* out, int64_t n_floats) {
@@ -2262,6 +2300,29 @@ extern "C" int nvl_get_mamba_state(nvl_model* m, int64_t seq_id, int layer, floa
     const float* src = m->ssm_state + (int64_t)it->second * m->ssm_slot_stride + (int64_t)m->layers[(size_t)layer].mamba_idx * m->ssm_layer_stride;
     NVL_HIP(hipMemcpy(out, src, (size_t)m->ssm_layer_stride * 4, hipMemcpyDeviceToHost));
     return (int)m->ssm_layer_stride;
+    NVL_CATCH(m)
+}
+
+extern "C" int nvl_get_weight(nvl_model* m, int kind, int layer, float* out, int64_t in_features, int64_t out_features) {
+    if (!m || !out) return NVL_ERR_INVALID;
+    DevTensor* t = tensor_slot(m, kind, layer);
+    if (!t || is_1d(kind)) return fail(m, NVL_ERR_INVALID, "nvl_get_weight: not a 2-D weight kind");
+    if (!t->present()) return fail(m, NVL_ERR_STATE, "nvl_get_weight: the tensor is not on the device (never uploaded, or fused away by nvl_finalize)");
+    if (t->rows != out_features || t->cols != in_features) return fail(m, NVL_ERR_INVALID, "nvl_get_weight: shape mismatch");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    NVL_HIP(hipStreamSynchronize(m->stream));
+    const int64_t N = t->rows, K = t->cols, n_el = t->rows_pad * K;
+    std::vector<char> raw((size_t)n_el * m->wsize);
+    NVL_HIP(hipMemcpy(raw.data(), t->p, raw.size(), hipMemcpyDeviceToHost));
+    for (int64_t n = 0; n < N; n++)
+        for (int64_t k = 0; k < K; k++) {
+            float v;
+            if (m->f32) v = ((const float*)raw.data())[n * K + k];
+            else { const uint32_t u = ((uint32_t)((const uint16_t*)raw.data())[fm_index(n, k, K)]) << 16; memcpy(&v, &u, 4); }
+            out[k * N + n] = v;      // the reference's [in, out]
+        }
+    return NVL_OK;
     NVL_CATCH(m)
 }
 
@@ -2513,7 +2574,11 @@ int runner_impl(nvl_model* m, int n_seqs, const int64_t* seq_ids, const int32_t*
             while (done < token_lens[i]) {
                 const int32_t n = (int32_t)std::min<int64_t>(m->opts.max_batch_tokens, token_lens[i] - done);
                 const int32_t p0 = done;
+                // hybrid models: the reference prefills the history in ONE Forward, whose Mamba2 convolution window spans
+                // the chunk seams (mamba2.go:183-254): chunks after the first take the previous chunk's tail (mamba.h)
+                m->conv_chain = done == 0 ? 1 : 2;
                 rc = nvl_forward(m, 1, &seq_ids[i], token_ptrs[i] + done, &n, &p0, 0, logits_out ? lg.data() : nullptr, &out);
+                m->conv_chain = 0;
                 if (rc) return rc;
                 done += n;
             }

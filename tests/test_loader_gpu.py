@@ -120,3 +120,69 @@ def test_plain_c_consumer_of_the_abi(gpu, tmp_path):
     assert "tok/s" in out.stderr
     bad = subprocess.run([str(exe), str(tmp_path / "nope"), "3", "1"], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "config" in bad.stderr
+
+
+def _get_weight(gpu, hm, slot, layer, n_in, n_out):
+    import ctypes as C
+    out = np.empty((n_in, n_out), np.float32)
+    gpu._lib.check(hm.lib.nvl_get_weight(hm.h, gpu._lib.SLOT_ID[slot], layer, out.ctypes.data_as(C.c_void_p), n_in, n_out), hm.h)
+    return out
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_reference_falcon_fixture_through_the_librarys_own_split(gpu, oracle, precision):
+    """purego/tensor/falcon_split_test.go:7-158 — the ONLY vectors the reference's tests hold on this path — replayed on
+    nvl_upload_falcon_qkv itself (round 2 replayed them on the oracle only): the fused query_key_value matrix goes in as
+    the reference holds it after Transpose ([hidden, (nH + 2) hd]), the device's Q and K|V weights are read back in the
+    reference's post-load layout (nvl_get_weight) and compared with the fixture's expectations and, element for element,
+    with the oracle's splitFalconQKV + combineMQAKV (generic_loader.go:705-765)."""
+    import ctypes as C
+    from pathlib import Path
+    g = np.load(Path(__file__).resolve().parent / "golden" / "falcon_split.npz")
+    exact = precision == "f32"                                # 999 / 10 r + h are not all bf16 numbers: bf16 compares rounded values
+
+    def rb(a):
+        return a if exact else gpu.synth.round_bf16(a)
+
+    def upload_and_read(nH, hd, hidden, qkv):
+        cfg = dict(gpu.synth.FULL_CONFIGS["falcon-7b"], num_layers=1, vocab_size=256, hidden=hidden, num_heads=nH,
+                   head_dim=hd, ffn_dim=4 * hidden, max_seq_len=64)
+        hm = gpu.HipTransformerModel(cfg, None, precision=precision, max_seqs=1, max_batch_tokens=64)
+        a = np.ascontiguousarray(qkv, np.float32)
+        gpu._lib.check(hm.lib.nvl_upload_falcon_qkv(hm.h, 0, a.ctypes.data_as(C.c_void_p)), hm.h)
+        q = _get_weight(gpu, hm, "wq", 0, hidden, nH * hd)
+        kv = _get_weight(gpu, hm, "wkv", 0, hidden, 2 * hd)
+        hm.close()
+        return q, kv
+
+    # (1) TestSplitFalconQKVRealDimensions (:102-158): Falcon-7B's own sizes, row 0 from the fixture
+    nH, hd, hidden = 71, 64, 4544
+    qkv = np.random.default_rng(3).standard_normal((hidden, (nH + 2) * hd), dtype=np.float32)
+    qkv = gpu.synth.round_bf16(qkv)
+    qkv[0] = g["row0_7b"]
+    q, kv = upload_and_read(nH, hd, hidden, qkv)
+    assert q.shape == (hidden, nH * hd) and kv.shape == (hidden, 2 * hd)                     # :141-143
+    for h in range(nH):
+        assert q[0, h * hd] == rb(np.float32(h))                                             # :146-152
+    assert kv[0, 0] == rb(np.float32(999.0)) and kv[0, hd] == rb(np.float32(888.0))          # :154-160
+    oq, ok, ov = oracle.split_falcon_qkv(qkv, hidden, nH, hd)
+    assert np.array_equal(q, rb(oq)) and np.array_equal(kv, rb(oracle.combine_mqa_kv(ok, ov)))
+    # (2) TestSplitFalconQKV (:7-98): the fixture's pattern — Q head h of row r holds 10 r + h, K 100 r, V 1000 r — and its
+    # expected values, at the smallest sizes the kernels take (the fixture's own 3 heads x 4 is below head_dim 64)
+    nH, hd, hidden = 3, 64, 192
+    assert g["qkv"].shape == (12, 20) and np.all(g["qkv"][2, 4:8] == 21) and np.all(g["qkv"][2, 12:16] == 200) and np.all(g["qkv"][2, 16:20] == 2000)
+    qkv = np.zeros((hidden, (nH + 2) * hd), np.float32)
+    for r in range(hidden):
+        for h in range(nH):
+            qkv[r, h * hd:(h + 1) * hd] = 10 * r + h
+        qkv[r, nH * hd:(nH + 1) * hd] = 100 * r
+        qkv[r, (nH + 1) * hd:] = 1000 * r
+    q, kv = upload_and_read(nH, hd, hidden, qkv)
+    for row in range(3):                                                                     # :68-98
+        for h in range(nH):
+            assert q[row, h * hd] == rb(g["q_want"][row, h])
+        assert kv[row, 0] == rb(g["k_want"][row]) and kv[row, hd] == rb(g["v_want"][row])
+    for r in range(hidden):
+        for h in range(nH):
+            assert np.all(q[r, h * hd:(h + 1) * hd] == rb(np.float32(10 * r + h)))
+        assert np.all(kv[r, :hd] == rb(np.float32(100 * r))) and np.all(kv[r, hd:] == rb(np.float32(1000 * r)))

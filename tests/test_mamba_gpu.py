@@ -130,6 +130,40 @@ def test_hybrid_greedy_fused_equals_stepwise_and_runner(gpu, oracle):
     hm.close()
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("variant", [0, 2])                                     # conv kernel 4 and 3
+def test_runner_chunked_prefill_of_a_long_history_matches_one_forward(gpu, oracle, precision, variant):
+    """A history longer than max_batch_tokens is prefilled in chunks by the runner; the reference runs ONE Forward over
+    it, whose Mamba2 convolution window spans what are chunk seams here (mamba2.go:183-254).  The chunks after the first
+    take the previous chunk's last K-1 raw xBC rows (mamba.h MambaArgs::chain): logits and the SSM state equal the
+    oracle's one-shot prefill — also with a last chunk shorter than the convolution window."""
+    cfg = gpu.synth.tiny_config("granite_hybrid", **VARIANTS[variant])
+    w = gpu.synth.make_weights(cfg, seed=17, scale=0.05)
+    tol = TOL[precision]
+    for ntok in (3 * 64 + 1, 2 * 64 + 37):                                     # last chunk of 1 token / of 37
+        hm = gpu.HipTransformerModel(cfg, w, precision=precision, max_seqs=2, max_batch_tokens=64)
+        om = oracle.OracleModel(cfg, w)
+        toks = np.random.default_rng(40 + ntok).integers(0, cfg["vocab_size"], ntok).tolist()
+        want = om.forward_with_cache(toks, om.new_cache(), 0)[-1]
+        runner = gpu.HipModelRunner(hm)
+        _, lg = runner.run([gpu.Sequence(seq_id=5, token_ids=toks)], True, return_logits=True)
+        assert hm.stats()["forward_calls"] == -(-ntok // 64)                   # it really was chunked
+        assert rel_err(lg[0], want) <= tol
+        for li, kind in enumerate(cfg["hybrid_layers"]):
+            if kind == "mamba":
+                assert rel_err(hm.get_mamba_state(5, li), om.mamba_state(li)) <= tol
+        # a plain multi-call nvl_forward keeps the reference's semantics (each call = one Forward: zero padding)
+        hm.seq_reset(6)
+        om2 = oracle.OracleModel(cfg, w)
+        kv = om2.new_cache()
+        om2.forward_with_cache(toks[:64], kv, 0)
+        want2 = om2.forward_with_cache(toks[64:100], kv, 64)[-1]
+        hm.forward_batch([6], [toks[:64]], [0], want_logits=False)
+        got2, _ = hm.forward_batch([6], [toks[64:100]], [64])
+        assert rel_err(got2[0], want2) <= tol
+        hm.close()
+
+
 def test_hybrid_is_refused_where_it_cannot_work(gpu):
     cfg = gpu.synth.tiny_config("granite_hybrid")
     with pytest.raises(gpu.NvlError):                       # per-sequence state lives in KV slots: no paged mode

@@ -353,6 +353,40 @@ def test_graph_replayed_decode_is_bit_identical_to_eager(gpu, oracle, family):
     hm.close()
 
 
+def test_fused_loop_graph_survives_a_longer_second_call(gpu, oracle):
+    """nvl_decode_greedy keeps its step tokens in a device ring that grows with n_steps x n_seqs; the captured step graph
+    holds the ring's address as a kernel argument, so growing the ring must drop the captured graphs (round-2 advisor
+    finding: a 4-step call followed by a 40-step call replayed a graph that wrote into the freed ring).  A short call, then
+    a longer one on the same model and batch, against stepwise nvl_forward on a second model."""
+    cfg, om, hm = build(gpu, oracle, "llama", "bf16")
+    hs = gpu.HipTransformerModel(cfg, gpu.synth.make_weights(cfg, seed=7, scale=0.05), precision="bf16", max_seqs=4,
+                                 max_batch_tokens=256)
+    r = np.random.default_rng(77)
+    prompts = [r.integers(0, cfg["vocab_size"], n).tolist() for n in (11, 30)]
+    for m_ in (hm, hs):
+        for i in range(2):
+            m_.seq_reset(i)
+    _, am = hm.forward_batch([0, 1], prompts, [0, 0])
+    _, am_s = hs.forward_batch([0, 1], prompts, [0, 0])
+    assert np.array_equal(am, am_s)
+    want = []
+    tok, pos = am_s, [len(p) for p in prompts]
+    old = gpu.lib().nvl_set_tuning(21, 0)             # the reference run: every launch eager, one nvl_forward per step
+    try:
+        for _ in range(4 + 40):
+            _, tok = hs.forward_batch([0, 1], [[int(t)] for t in tok], pos)
+            want.append(tok.copy()); pos = [p + 1 for p in pos]
+    finally:
+        gpu.lib().nvl_set_tuning(21, old)
+    want = np.stack(want)
+    hm.reset_stats()
+    a = hm.decode_greedy([0, 1], am, 4)               # steps 2.. are captured + replayed; ring = 8 ints
+    b = hm.decode_greedy([0, 1], a[-1], 40)           # the ring grows: the captured step must not be replayed as it was
+    assert hm.stats()["graph_replays"] >= 30
+    assert np.array_equal(a, want[:4]) and np.array_equal(b, want[4:])
+    hm.close(); hs.close()
+
+
 @pytest.mark.parametrize("family,hd", [("llama", 64), ("llama", 128), ("falcon", 64)])
 def test_long_context_decode_splits_keys_over_workgroups(gpu, oracle, family, hd):
     """Decode over >= 1024 cached keys in a small batch deals the key tiles over several workgroups per (sequence,
