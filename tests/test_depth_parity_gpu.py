@@ -1,13 +1,23 @@
 """Parity at FULL DEPTH, per layer (round-3 item: "earn the tolerance").
 
-The error model and its bounds are DESIGN.md §3's, written down before these measurements were taken:
-    eps = 2^-9 (bf16 half-ulp);  residual stream after layer l (0-based):
-        RMS(error) / RMS(oracle stream)        <= e(l) = eps * sqrt(2 (l + 1))
-        max |error| / max |oracle stream|      <= 2 e(l)
-    last-row logits of an L-layer model:
-        RMS(error) / RMS(oracle logits)        <= eps * sqrt(2 L + 1)
-        max |error| / max |logit|              <= 2 eps * sqrt(2 L + 1)   (x sqrt(ln N / ln V) over N >> V logits)
-    fp32 parity mode: 1e-4 (max norm) at every layer and depth.
+DESIGN.md §3 holds the error model.  Its first version was written down BEFORE any per-layer measurement, with the wrong
+constant (2^-9 taken for bf16's unit roundoff; bf16 keeps 8 significant bits: it is 2^-8) and a sqrt growth law: the first
+device run sat at 2.1x that bound at layer 0 and 1.2x at layer 15.  scripts/bf16_error_budget.py then rebuilt the path's
+roundings on the CPU (tests/bf16_emulator.py: float64 with a bf16 rounding at the eight points per layer where a value
+becomes an MFMA operand) — and reproduces the device's error against the oracle to two digits at every one of Llama-3.2-1B's
+16 layers (5.7e-3 at layer 0 ... 1.4e-2 at layer 15, last-row logits 1.5e-2).  So the bounds asserted here are:
+
+  * Llama-family models (the emulator covers them): the device's per-layer RMS error vs the ORACLE <= 1.15 x the
+    emulator's error vs the same oracle values, layer by layer, prefill and decode; last-row logits RMS <= 1.15 x, max
+    <= 1.25 x the emulator's (the max of 128256 errors is an extreme-value statistic: ~5 % run-to-run).  An extra rounding
+    point, a lost fp32 accumulation or a wrong scale anywhere in the 16 layers shows up as a ratio > 1.
+  * every family, closed form fitted to that curve (eps = 2^-8):
+        residual stream after layer l:  RMS(error) / RMS(oracle stream)  <= B(l) = 1.25 x 1.5 eps (l + 1)^(1/3)
+                                        max |error| / max |oracle stream| <= 1.5 B(l)
+        last-row logits, L layers:      RMS <= B(L),  max <= 1.5 B(L)  (x sqrt(ln N / ln V) over N >> V logits)
+    (1.5 eps = the quadrature sum of the eight roundings of one layer, 5.7e-3; the cube-root growth is what carrying the
+    earlier layers' errors through the later ones adds while the stream's own RMS grows like sqrt(l + 1).)
+  * fp32 parity mode: 1e-4 (max norm) at every layer and depth.
 
 What runs:
   * Llama-3.2-1B (BASELINE configs[1], 16 layers, the bench model) and GPT-2 (configs[0], 12 layers): the CPU oracle at full
@@ -18,7 +28,7 @@ What runs:
     the batch sizes profiles/r02_other_configs.txt was measured at — every layer of a B x 64-token prefill (the tile kernels)
     and of a decode step (the decode kernels) bf16 vs the fp32 mode, and the last-row logits of a B x 256 prefill + 4
     teacher-forced decode steps.
-The growth curves are printed (pytest -s shows them; DESIGN.md §9c records what round 3 measured).
+The growth curves are printed (pytest -s shows them; DESIGN.md §3 records what round 3 measured).
 """
 import math
 import os
@@ -26,17 +36,20 @@ import os
 import numpy as np
 import pytest
 
+import bf16_emulator as emu
+
 pytestmark = pytest.mark.gpu
-EPS = 2.0 ** -9
+EPS = 2.0 ** -8
 TOL_F32 = 1e-4
+MAX_OVER_RMS = 1.5
 
 
 def e_rms(layer):                 # residual stream after layer `layer` (0-based)
-    return EPS * math.sqrt(2.0 * (layer + 1))
+    return 1.25 * 1.5 * EPS * (layer + 1.0) ** (1.0 / 3.0)
 
 
 def logit_rms(L):
-    return EPS * math.sqrt(2.0 * L + 1.0)
+    return e_rms(L)
 
 
 def rms(a):
@@ -67,19 +80,20 @@ def check_layers(tag, got_h, want_h, capsys, f32=False):
             assert mm[l] <= TOL_F32, (tag, l, mm[l])
         else:
             assert rr[l] <= e_rms(l), (tag, "rms", l, rr[l], e_rms(l))
-            assert mm[l] <= 2 * e_rms(l), (tag, "max", l, mm[l], 2 * e_rms(l))
+            assert mm[l] <= MAX_OVER_RMS * e_rms(l), (tag, "max", l, mm[l], MAX_OVER_RMS * e_rms(l))
     return rr, mm
 
 
 def check_logits(tag, got, want, L, capsys, f32=False, n_factor=1.0):
     r, m = rel_rms(got, want), rel_max(got, want)
     with capsys.disabled():
-        print(f"[depth parity] {tag}: logits RMS rel err {r:.2e} (bound {logit_rms(L):.2e}), max rel err {m:.2e} (bound {2 * logit_rms(L) * n_factor:.2e})")
+        print(f"[depth parity] {tag}: logits RMS rel err {r:.2e} (bound {logit_rms(L):.2e}), max rel err {m:.2e} (bound {MAX_OVER_RMS * logit_rms(L) * n_factor:.2e})")
     if f32:
         assert m <= TOL_F32, (tag, m)
     else:
         assert r <= logit_rms(L), (tag, r)
-        assert m <= 2 * logit_rms(L) * n_factor, (tag, m)
+        assert m <= MAX_OVER_RMS * logit_rms(L) * n_factor, (tag, m)
+    return r, m
 
 
 def tapped_forward(model, seq_id, toks, pos):
@@ -110,16 +124,36 @@ def test_full_depth_per_layer_vs_oracle(gpu, oracle, capsys, key):
     finally:
         oracle.set_threads(1)
     del om
+    # the emulation of the product path's rounding points, against the same oracle values (Llama family only)
+    em = None
+    if key.startswith("llama"):
+        e_h, e_lg = emu.forward(cfg, w, prompt)
+        e_h2, e_lg2 = emu.forward(cfg, w, prompt + [tok])          # causal: row 24 of a 25-token pass IS the decode step
+        em = dict(pre=[rel_rms(e_h[l], want_h[l]) for l in range(L)], dec=[rel_rms(e_h2[l][24:], want_h2[l]) for l in range(L)],
+                  lg=(rel_rms(e_lg, want[-1]), rel_max(e_lg, want[-1])), lg2=(rel_rms(e_lg2, want2[-1]), rel_max(e_lg2, want2[-1])))
+        with capsys.disabled():
+            print(f"\n[depth parity] {key} EMULATED rounding points vs oracle, prefill: " + " ".join(f"{v:.1e}" for v in em["pre"]))
+            print(f"[depth parity] {key} EMULATED rounding points vs oracle, decode:  " + " ".join(f"{v:.1e}" for v in em["dec"]))
+            print(f"[depth parity] {key} EMULATED logits: prefill RMS {em['lg'][0]:.2e} max {em['lg'][1]:.2e}; decode RMS {em['lg2'][0]:.2e} max {em['lg2'][1]:.2e}")
     for precision in ("bf16", "f32"):
         f32 = precision == "f32"
         hm = gpu.HipTransformerModel(cfg, w, precision=precision, max_seqs=2, max_batch_tokens=64)
         hm.seq_reset(1)
         got, got_h = tapped_forward(hm, 1, prompt, 0)
-        check_layers(f"{key} {precision} prefill 24 tokens vs oracle", got_h, want_h, capsys, f32)
-        check_logits(f"{key} {precision} prefill", got, want[-1], L, capsys, f32)
+        rr, _ = check_layers(f"{key} {precision} prefill 24 tokens vs oracle", got_h, want_h, capsys, f32)
+        lr = check_logits(f"{key} {precision} prefill", got, want[-1], L, capsys, f32)
         got2, got_h2 = tapped_forward(hm, 1, [tok], 24)
-        check_layers(f"{key} {precision} decode step vs oracle", got_h2, want_h2, capsys, f32)
-        check_logits(f"{key} {precision} decode", got2, want2[-1], L, capsys, f32)
+        rr2, _ = check_layers(f"{key} {precision} decode step vs oracle", got_h2, want_h2, capsys, f32)
+        lr2 = check_logits(f"{key} {precision} decode", got2, want2[-1], L, capsys, f32)
+        if em and not f32:
+            with capsys.disabled():
+                print(f"[depth parity] {key} device / emulated RMS error, prefill: " + " ".join(f"{a / b:.2f}" for a, b in zip(rr, em["pre"])))
+                print(f"[depth parity] {key} device / emulated RMS error, decode:  " + " ".join(f"{a / b:.2f}" for a, b in zip(rr2, em["dec"])))
+            for l in range(L):
+                assert rr[l] <= 1.15 * em["pre"][l], ("prefill vs emulator", l, rr[l], em["pre"][l])
+                assert rr2[l] <= 1.15 * em["dec"][l], ("decode vs emulator", l, rr2[l], em["dec"][l])
+            for (r_, m_), (er, emx) in ((lr, em["lg"]), (lr2, em["lg2"])):
+                assert r_ <= 1.15 * er and m_ <= 1.25 * emx, ("logits vs emulator", r_, er, m_, emx)
         # the taps do not change the path: an untapped call on a fresh slot gives the same logits bit for bit
         hm.seq_reset(0)
         plain, _ = hm.forward_batch([0], [prompt], [0])
