@@ -21,8 +21,8 @@ def round_bf16(a):
     return (((u + r) >> 16) << 16).astype(np.uint32).view(np.float32)
 
 
-def rb(a, on):
-    return round_bf16(np.asarray(a, np.float32)).astype(np.float64) if on else np.asarray(a, np.float64)
+def rb(a, on, dt=np.float64):
+    return round_bf16(np.asarray(a, np.float32)).astype(dt) if on else np.asarray(a, dt)
 
 
 def _rms(v, g, eps):
@@ -30,57 +30,66 @@ def _rms(v, g, eps):
 
 
 def layer(x, w, li, cfg, sw):
-    """one decoder layer on the [S, H] stream x (float64); sw = the set of rounding points that are on"""
+    """one decoder layer on the [S, H] stream x; sw = the set of rounding points that are on.  Computes in x.dtype:
+    float64 (the default of forward(): "exact" beside the roundings) or float32 (the 7-8 B-parameter configs: numpy sgemm,
+    relative error ~1e-6, three orders below one bf16 rounding — and no float64 copy of every weight matrix)"""
     nH, nKV, hd, F = cfg["num_heads"], cfg["num_kv_heads"], cfg["head_dim"], cfg["ffn_dim"]
     S = x.shape[0]
     eps = cfg["norm_eps"]
-    xn = rb(_rms(x, w[("attn_norm_w", li)].astype(np.float64), eps), "xn" in sw)
-    q = xn @ w[("wq", li)].astype(np.float64)
-    k = xn @ w[("wk", li)].astype(np.float64)
-    v = xn @ w[("wv", li)].astype(np.float64)
+    dt = x.dtype
+
+    def W(slot):
+        return w[(slot, li)].astype(dt, copy=False)
+
+    def r(a, point):
+        return rb(a, point in sw, dt)
+    xn = r(_rms(x, W("attn_norm_w"), eps), "xn")
+    q = xn @ W("wq")
+    k = xn @ W("wk")
+    v = xn @ W("wv")
     half = hd // 2
     inv = 1.0 / cfg["rope_base"] ** (np.arange(half) * 2.0 / hd)
     ang = np.arange(S)[:, None] * inv[None, :]
-    cos = np.concatenate([np.cos(ang), np.cos(ang)], -1).astype(np.float32).astype(np.float64)   # fp32 tables (rope.go:18-50)
-    sin = np.concatenate([np.sin(ang), np.sin(ang)], -1).astype(np.float32).astype(np.float64)
+    cos = np.concatenate([np.cos(ang), np.cos(ang)], -1).astype(np.float32).astype(dt)   # fp32 tables (rope.go:18-50)
+    sin = np.concatenate([np.sin(ang), np.sin(ang)], -1).astype(np.float32).astype(dt)
 
     def rope(t, heads):
         t = t.reshape(S, heads, hd)
         rot = np.concatenate([-t[..., half:], t[..., :half]], -1)
         return t * cos[:, None, :] + rot * sin[:, None, :]
-    q = rb(rope(q, nH), "q" in sw)
-    k = rb(rope(k, nKV), "k" in sw)
-    v = rb(v.reshape(S, nKV, hd), "v" in sw)
+    q = r(rope(q, nH), "q")
+    k = r(rope(k, nKV), "k")
+    v = r(v.reshape(S, nKV, hd), "v")
     g = nH // nKV
-    ao = np.zeros((S, nH, hd))
+    ao = np.zeros((S, nH, hd), dt)
     mask = np.tril(np.ones((S, S), bool))
     scale = cfg.get("attention_multiplier") or 1.0 / np.sqrt(hd)
     for h in range(nH):
         s = np.where(mask, q[:, h, :] @ k[:, h // g, :].T * scale, -np.inf)
-        p = rb(np.exp(s - s.max(-1, keepdims=True)), "p" in sw)
+        p = r(np.exp(s - s.max(-1, keepdims=True)), "p")
         ao[:, h, :] = (p @ v[:, h // g, :]) / p.sum(-1, keepdims=True)      # row sums of the rounded p (ones . P^T on the MFMA pipe)
-    ao = rb(ao.reshape(S, nH * hd), "ao" in sw)
-    x = x + ao @ w[("wo", li)].astype(np.float64)
-    xn2 = rb(_rms(x, w[("ffn_norm_w", li)].astype(np.float64), eps), "xn2" in sw)
-    gu = xn2 @ w[("w1", li)].astype(np.float64)
+    ao = r(ao.reshape(S, nH * hd), "ao")
+    x = x + ao @ W("wo")
+    xn2 = r(_rms(x, W("ffn_norm_w"), eps), "xn2")
+    gu = xn2 @ W("w1")
     gate, up = gu[:, :F], gu[:, F:]
-    hh = rb(gate / (1.0 + np.exp(-gate)) * up, "h" in sw)
-    return x + hh @ w[("w2", li)].astype(np.float64)
+    hh = r(gate / (1.0 + np.exp(-gate)) * up, "h")
+    return x + hh @ W("w2")
 
 
-def forward(cfg, w, tokens, sw=ALL, last_logits=True):
-    """-> (hidden [L, S, H] float64, last-row logits [V] float64 or None)"""
+def forward(cfg, w, tokens, sw=ALL, last_logits=True, dtype=np.float64):
+    """-> (hidden [L, S, H], last-row logits [V] or None) in `dtype`"""
     assert cfg["attention_type"] == "gqa" and cfg["norm_type"] == "rmsnorm" and cfg["activation_type"] == "swiglu" and \
         cfg["block_style"] == "sequential" and cfg["position_type"] == "rope" and not cfg.get("use_moe")
     sw = set(sw)
-    x = w[("tok_emb", 0)][np.asarray(tokens)].astype(np.float64)
+    x = w[("tok_emb", 0)][np.asarray(tokens)].astype(dtype)
     hidden = []
     for li in range(cfg["num_layers"]):
         x = layer(x, w, li, cfg, sw)
         hidden.append(x)
     logits = None
     if last_logits:
-        xl = rb(_rms(x[-1:], w[("final_norm_w", 0)].astype(np.float64), cfg["norm_eps"]), "xl" in sw)
+        xl = rb(_rms(x[-1:], w[("final_norm_w", 0)].astype(dtype), cfg["norm_eps"]), "xl" in sw, dtype)
         head = w[("lm_head", 0)] if ("lm_head", 0) in w else w[("tok_emb", 0)].T      # tied: generic_loader.go:255-259
-        logits = (xl @ head.astype(np.float64))[0]
+        logits = (xl @ head.astype(dtype, copy=False))[0]
     return np.stack(hidden), logits

@@ -3,7 +3,7 @@
 point bench.py measures.
 
   (a) the CPU oracle runs one 24-token sequence through all 16 layers and the 128256-row LM head: the bf16 product path's
-      logits are within the bound DESIGN.md §3's error model gives for 16 layers (2.8e-2 max, 5e-3 RMS: asserted), the fp32
+      logits are within the bound DESIGN.md §3's error model gives for 16 layers (2e-2 max, 5e-3 RMS: asserted), the fp32
       parity mode's within 1e-4;
   (b) the whole 32 x 512 batch: bf16 logits vs the fp32 parity mode on the device (which (a) and the small-model tests
       tie to the oracle) within the bf16 tolerance, for the prefill and along the decode;
@@ -25,12 +25,13 @@ TOL_BF16, TOL_F32 = 1.5e-2, 1e-4
 # Bounds for THIS depth from DESIGN.md §3 (tests/test_depth_parity_gpu.py checks the model layer by layer, and the device
 # against a CPU emulation of its rounding points, which puts the EXPECTED last-row error at 16 layers at 1.45e-2 RMS /
 # 1.46e-2 max — round 2 measured 1.4e-2 .. 1.7e-2):
-#   one row of V logits:                 max |error| / max |logit| <= 1.5 B(16),  B(L) = 1.25 x 1.5 x 2^-8 x (L + 1)^(1/3)  -> 2.8e-2
+#   one row of V logits:                 max |error| / max |logit| <= 1.25 x the emulated 1.46e-2 (the max of 128256 errors
+#                                        moves ~5 % run to run) = 1.83e-2 ... stated as 2e-2
 #   the whole 32 x 129-row run:          stated 3e-2 since round 2 (measured 1.85e-2 .. 2.26e-2: the largest of N V errors sits
 #                                        sqrt(ln(N V) / ln V) = 1.31 further out than one row's), kept
 #   RMS(error) / max |logit|:            stated 5e-3 since round 2 (measured 3.5e-3), kept
 L_BENCH, V_BENCH = 16, 128256
-TOL_BF16_ROW_MAX = 1.5 * 1.25 * 1.5 * 2.0 ** -8 * (L_BENCH + 1) ** (1.0 / 3.0)
+TOL_BF16_ROW_MAX = 2e-2
 TOL_BF16_BATCH_MAX = 3e-2
 TOL_BF16_BATCH_RMS = 5e-3
 

@@ -11,12 +11,15 @@ becomes an MFMA operand) — and reproduces the device's error against the oracl
     emulator's error vs the same oracle values, layer by layer, prefill and decode; last-row logits RMS <= 1.15 x, max
     <= 1.25 x the emulator's (the max of 128256 errors is an extreme-value statistic: ~5 % run-to-run).  An extra rounding
     point, a lost fp32 accumulation or a wrong scale anywhere in the 16 layers shows up as a ratio > 1.
-  * every family, closed form fitted to that curve (eps = 2^-8):
-        residual stream after layer l:  RMS(error) / RMS(oracle stream)  <= B(l) = 1.25 x 1.5 eps (l + 1)^(1/3)
+  * every family, closed-form envelope (eps = 2^-8):
+        residual stream after layer l:  RMS(error) / RMS(oracle stream)  <= B(l) = 1.25 x 1.5 eps sqrt(l + 1)
                                         max |error| / max |oracle stream| <= 1.5 B(l)
         last-row logits, L layers:      RMS <= B(L),  max <= 1.5 B(L)  (x sqrt(ln N / ln V) over N >> V logits)
-    (1.5 eps = the quadrature sum of the eight roundings of one layer, 5.7e-3; the cube-root growth is what carrying the
-    earlier layers' errors through the later ones adds while the stream's own RMS grows like sqrt(l + 1).)
+    (1.5 eps = the quadrature sum of the eight roundings of one layer, 5.7e-3 .. 6.0e-3 measured; sqrt(l + 1) = every
+    layer adding that much, in quadrature, to a stream that does not outgrow it.  How much slower the real curve grows
+    depends on the model: Llama-3.2-1B's goes like (l + 1)^(1/3) — its stream's RMS grows like sqrt(l + 1) —, the 4096-wide
+    Llama-3-8B shapes with the same N(0, 0.02^2) synthetic weights have a per-projection gain of 0.02 sqrt(4096) = 1.28 > 1
+    and reach 2.7e-2 at layer 31, (l + 1)^0.43; GPT-2, Falcon and Granite stay under 6e-3 at any depth.)
   * fp32 parity mode: 1e-4 (max norm) at every layer and depth.
 
 What runs:
@@ -45,7 +48,7 @@ MAX_OVER_RMS = 1.5
 
 
 def e_rms(layer):                 # residual stream after layer `layer` (0-based)
-    return 1.25 * 1.5 * EPS * (layer + 1.0) ** (1.0 / 3.0)
+    return 1.25 * 1.5 * EPS * math.sqrt(layer + 1.0)
 
 
 def logit_rms(L):
@@ -199,16 +202,33 @@ def test_full_depth_big_configs(gpu, oracle, capsys, key):
         want2, want_h2 = om.forward_with_cache([tok], kv, 8, want_hidden=True, last_only=True)
     finally:
         oracle.set_threads(1)
+    em = None
+    if key.startswith("llama"):      # the emulator covers the Llama family: the sharp bound (float32 compute: 32 GB of weights)
+        e_h, e_lg = emu.forward(cfg, host_w, prefix + [tok], dtype=np.float32)
+        em = dict(pre=[rel_rms(e_h[l][:8], want_h[l]) for l in range(L)], dec=[rel_rms(e_h[l][8:], want_h2[l]) for l in range(L)],
+                  lg2=(rel_rms(e_lg, want2[-1]), rel_max(e_lg, want2[-1])))
+        with capsys.disabled():
+            print(f"\n[depth parity] {key} EMULATED rounding points vs oracle, prefill: " + " ".join(f"{v:.1e}" for v in em["pre"]))
+            print(f"[depth parity] {key} EMULATED rounding points vs oracle, decode:  " + " ".join(f"{v:.1e}" for v in em["dec"]))
+            print(f"[depth parity] {key} EMULATED logits, decode: RMS {em['lg2'][0]:.2e} max {em['lg2'][1]:.2e}")
     del om, host_w
     for model, f32 in ((hb, False), (hf, True)):
         tag = f"{key} {'f32' if f32 else 'bf16'}"
         model.seq_reset(B)
         got, got_h = tapped_forward(model, B, prefix, 0)
-        check_layers(f"{tag} prefill 8 tokens vs oracle", got_h, want_h, capsys, f32)
+        rr, _ = check_layers(f"{tag} prefill 8 tokens vs oracle", got_h, want_h, capsys, f32)
         check_logits(f"{tag} prefill", got, want[-1], L, capsys, f32)
         got2, got_h2 = tapped_forward(model, B, [tok], 8)
-        check_layers(f"{tag} decode step vs oracle", got_h2, want_h2, capsys, f32)
-        check_logits(f"{tag} decode", got2, want2[-1], L, capsys, f32)
+        rr2, _ = check_layers(f"{tag} decode step vs oracle", got_h2, want_h2, capsys, f32)
+        lr2 = check_logits(f"{tag} decode", got2, want2[-1], L, capsys, f32)
+        if em and not f32:
+            with capsys.disabled():
+                print(f"[depth parity] {key} device / emulated RMS error, prefill: " + " ".join(f"{a / b:.2f}" for a, b in zip(rr, em["pre"])))
+                print(f"[depth parity] {key} device / emulated RMS error, decode:  " + " ".join(f"{a / b:.2f}" for a, b in zip(rr2, em["dec"])))
+            for l in range(L):
+                assert rr[l] <= 1.15 * em["pre"][l], ("prefill vs emulator", l, rr[l], em["pre"][l])
+                assert rr2[l] <= 1.15 * em["dec"][l], ("decode vs emulator", l, rr2[l], em["dec"][l])
+            assert lr2[0] <= 1.15 * em["lg2"][0] and lr2[1] <= 1.25 * em["lg2"][1], ("logits vs emulator", lr2, em["lg2"])
 
     # ---- (b) every layer at the batch size: B x 64-token prefill (tile kernels) and a decode step, bf16 vs fp32 mode ----
     ids = list(range(B))
