@@ -257,6 +257,12 @@ int nvl_decode_greedy(nvl_model* m, int n_seqs, const int64_t* seq_ids, const in
  * exactly what an untapped call runs; adds still pending for the next norm are included in the copy only. */
 int nvl_set_debug(nvl_model* m, int keep_hidden);
 int nvl_get_hidden(nvl_model* m, int layer, float* out, int64_t n_floats);
+/* Measurement: nvl_set_debug(m, 4) makes the decode-sized projection and attention kernels of the following forward calls
+ * (eager launches, no graph replay) record, per workgroup, the chip's 100 MHz constant clock at six points of their life —
+ * entered / first loads issued / first data used / own stream done / workgroup's stream done / stores retired.
+ * nvl_get_stamps returns the launches recorded so far: recs[3 i] = {site (nvl_kernel_site_name), phase, workgroups}, and the
+ * stamps [workgroups][8] of the launches back to back.  scripts/decode_timeline.py prints the step's timeline from them. */
+int nvl_get_stamps(nvl_model* m, int32_t* recs, int rec_cap, uint64_t* stamps, int64_t stamp_cap);
 /* Debug/parity: copy a sequence's cache for one layer as the reference lays it out,
  * K and V each [nKV, T, hd] fp32 (kv_cache.go:5-6).  Returns T. */
 int nvl_get_kv(nvl_model* m, int64_t seq_id, int layer, float* k_out, float* v_out);

@@ -134,6 +134,7 @@ def lib():
     L.nvl_get_kv.argtypes = [vp, i64, C.c_int, vp, vp]
     L.nvl_get_mamba_state.argtypes = [vp, i64, C.c_int, vp]
     L.nvl_get_weight.argtypes = [vp, C.c_int, C.c_int, vp, i64, i64]
+    L.nvl_get_stamps.argtypes = [vp, vp, C.c_int, vp, i64]
     L.nvl_runner_run.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp]
     L.nvl_decode_sampled.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(SamplingParamsC), vp, vp, vp, vp]
     L.nvl_sample.argtypes = [vp, C.c_int, C.POINTER(SamplingParamsC), vp, vp, vp, vp]

@@ -52,6 +52,7 @@ struct AttnArgs {
     // takes a ticket from part_cnt[seq * gridDim.x + blockIdx.x]; the workgroup that draws the last one combines them in z order.
     float* part;
     int32_t* part_cnt;    // zero between launches
+    unsigned long long* stamps;   // diagnostic runs: per-workgroup time stamps (common.h nvl_stamp), else NULL
 };
 template <int HD> constexpr int attn_part_floats() { return (HD / 16) * 64 * 4 + 32; }
 
@@ -390,6 +391,29 @@ __device__ __forceinline__ void rope_pair8(const float* row, const float* cs, co
     }
 }
 
+// the same in two steps — issue the loads, do the arithmetic later (the decode kernel puts its K/V stream in between)
+struct RopeRaw { f32x4 a0, a1, b0, b1, c0, c1, s0, s1; };
+__device__ __forceinline__ void rope_load8(const float* row, const float* cs, const float* sn, int d0, int half, RopeRaw& r) {
+    r.a0 = *(const f32x4*)(row + d0); r.a1 = *(const f32x4*)(row + d0 + 4);
+    r.b0 = *(const f32x4*)(row + d0 + half); r.b1 = *(const f32x4*)(row + d0 + half + 4);
+    if (cs) {
+        r.c0 = *(const f32x4*)(cs + d0); r.c1 = *(const f32x4*)(cs + d0 + 4);
+        r.s0 = *(const f32x4*)(sn + d0); r.s1 = *(const f32x4*)(sn + d0 + 4);
+    }
+}
+__device__ __forceinline__ void rope_math8(const RopeRaw& r, bool rot, bf16x8& lo, bf16x8& hi) {
+    f32x4 yl0 = r.a0, yl1 = r.a1, yh0 = r.b0, yh1 = r.b1;
+    if (rot) {
+        yl0 = r.a0 * r.c0 + (-r.b0) * r.s0; yl1 = r.a1 * r.c1 + (-r.b1) * r.s1;
+        yh0 = r.b0 * r.c0 + r.a0 * r.s0;    yh1 = r.b1 * r.c1 + r.a1 * r.s1;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        lo[e] = (bf16_t)yl0[e]; lo[4 + e] = (bf16_t)yl1[e];
+        hi[e] = (bf16_t)yh0[e]; hi[4 + e] = (bf16_t)yh1[e];
+    }
+}
+
 // combine of a split decode launch: the nsplit partial results of one (sequence, kv head, query tile), in workgroup order
 // whichever workgroup runs it.  One wave, the lanes of real heads; lane (fq, fg) as in the kernel's own combine.
 template <int HD>
@@ -418,8 +442,14 @@ __device__ __forceinline__ void attn_decode_merge(const AttnArgs& p, int pair, i
         act_store4<bf16_t>((bf16_t*)p.out, tok, head * HD + d * 16 + fg * 4, p.out_stride, O[d] * inv);
 }
 
-template <int HD, int NW, bool FUSED>
-__global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
+// The six leading arguments repeat fields of AttnArgs: the library is built with -amdgpu-kernarg-preload-count=6, so they
+// sit in SGPRs when a wave starts and the two scalar loads every wave needs before it can issue its first K/V load (the
+// sequence's position, the block id of its first tile) leave at once — with everything inside the struct the compiler
+// fetched the argument block in two dependent pieces first (in-kernel stamps: 2.4 us from entry to the first vector load
+// at B = 1, against 0.4 us in the projection kernels).
+template <int HD, int NW, bool FUSED, bool STAMP = false>
+__global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(const int32_t* __restrict__ a_seq_pos, const int32_t* __restrict__ a_blk_table,
+                                                                   int a_tbl_stride, int a_bs_shift, int a_Tmax, int a_group, AttnArgs p) {
     constexpr int KS = HD / 32, DT = HD / 16, HALF = HD / 2, CPR = HD / 8, KPI = 64 / CPR, NVL = 64 / KPI;
     constexpr int NT2 = HD <= 64 ? 2 : 1;                    // key tiles whose loads are in flight together, per wave
     constexpr int TILE_BYTES = 64 * HD * 2;
@@ -428,12 +458,27 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
     __shared__ float red_l[NW][16];
     // grid.x = kv head x query tile: a workgroup takes 16 of the group's query heads (GQA / MHA: one tile; Falcon's MQA:
     // 71 heads = 5 tiles that stream the same K/V — it is tiny next to the weights — from L2)
-    const int QT = (p.group + 15) >> 4;
+    const int swg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    NvlStampsT<STAMP> stamps(p.stamps, swg);          // (diagnostic instantiation only: see common.h)
+    const int QT = (a_group + 15) >> 4;
     const int seq = blockIdx.y, kvh = blockIdx.x / QT, qt = blockIdx.x - kvh * QT;
-    const int32_t* tbl = p.blk_table + (int64_t)seq * p.tbl_stride;
-    const int tok = p.seq_tok_start[seq], pos0 = p.seq_pos[seq];
+    const int32_t* tbl = a_blk_table + (int64_t)seq * a_tbl_stride;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ONE scalar round trip for everything the first K/V loads need: the token row, the position, and the block ids of this
+    // wave's first tiles (which do not depend on the position).  Left to itself the compiler sinks the block-id loads behind
+    // the position's wait and the tile-count branch (two more dependent scalar round trips before the first vector load:
+    // +0.7 us per launch at B = 1).
+    constexpr int NT2_ = HD <= 64 ? 2 : 1;
+    const int vw_ = blockIdx.z * NW + wave, nvw_ = NW * gridDim.z;
+    const int tok = seq, pos0 = a_seq_pos[seq];              // (decode launches carry one token per sequence, in sequence order)
+    int first_blk[NT2_];
+#pragma unroll
+    for (int h = 0; h < NT2_; h++) {
+        const int key = (vw_ + h * nvw_) * 64;
+        const int bi = a_bs_shift >= 0 ? (key >> a_bs_shift) : key / a_Tmax;
+        first_blk[h] = tbl[min(bi, a_tbl_stride - 1)];
+    }
     const int fq = lane & 15, fg = lane >> 4;                // MFMA role: query head qt*16 + fq of the group, k group fg
     const int dch = lane % CPR, ksub = lane / CPR;           // row role: 16-byte chunk dch of key row ksub (+ i*KPI)
     const bool row_ok = qt * 16 + fq < p.group;
@@ -445,28 +490,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
     // (sequence, kv head).  gridDim.z > 1 (long contexts in small batches: one workgroup would pull the whole K/V of its
     // head through one CU, ~50 GB/s) leaves partial results for attn_decode_merge_kernel.
     const int vw = blockIdx.z * NW + wave, nvw = NW * gridDim.z;
-    // FUSED: the new token's K row (RoPE applied) as this lane's MFMA operand chunks, and chunk dch of its V row
+    // (FUSED: the new token's q / k / v are fetched and rotated AFTER the first round's K/V loads are issued: below)
     bf16x8 knew[KS];
     bf16x8 vnew8;
-    if (FUSED) {
-        const float* row = p.qkv + (int64_t)tok * p.qkv_stride;
-        const float* cs = p.cos_t ? p.cos_t + (int64_t)pos0 * HD : nullptr;
-        const float* sn = p.sin_t ? p.sin_t + (int64_t)pos0 * HD : nullptr;
-#pragma unroll
-        for (int ks = 0; ks < KS / 2; ks++) {
-            rope_pair8(row + head * HD, cs, sn, ks * 32 + fg * 8, HALF, qf[ks], qf[ks + KS / 2]);
-            rope_pair8(row + (p.nH + kvh) * HD, cs, sn, ks * 32 + fg * 8, HALF, knew[ks], knew[ks + KS / 2]);
-        }
-        const float* vrow = row + (p.nH + p.nKV + kvh) * HD + dch * 8;
-        const f32x4 v0 = *(const f32x4*)vrow, v1 = *(const f32x4*)(vrow + 4);
-#pragma unroll
-        for (int e = 0; e < 4; e++) { vnew8[e] = (bf16_t)v0[e]; vnew8[4 + e] = (bf16_t)v1[e]; }
-    } else {
-        const bf16_t* qp = (const bf16_t*)p.q + (int64_t)tok * p.q_stride + head * HD;
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) qf[ks] = *(const bf16x8*)(qp + ks * 32 + fg * 8);
-    }
-
     f32x4 o[DT];
 #pragma unroll
     for (int d = 0; d < DT; d++) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -480,13 +506,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
 #pragma unroll
     for (int d = 0; d < DT; d++) v_off[d] = 16 * kv_img_chunk<HD>(4 * fg + q4, 2 * d + (p4 >> 1)) + 8 * (p4 & 1);
 
-    // the block ids of this wave's first tiles do not depend on the sequence length: fetch them beside it, not after it
-    int first_blk[NT2];
-#pragma unroll
-    for (int h = 0; h < NT2; h++) first_blk[h] = tbl[min(kv_block_index(p, (vw + h * nvw) * 64), p.tbl_stride - 1)];
     bf16x8 kf[NT2][4][KS];
     bf16x8 vch[NT2][NVL];
-    for (int kt0 = vw; kt0 < n_kt; kt0 += NT2 * nvw) {
+    // the K / V loads of one round (NT2 tiles of this wave): addresses depend on scalars only
+    auto issue_round = [&](int kt0) {
 #pragma unroll
         for (int h = 0; h < NT2; h++) {
             const int kt = kt0 + h * nvw;
@@ -504,6 +527,62 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
 #pragma unroll
             for (int i = 0; i < NVL; i++) vch[h][i] = *(const bf16x8*)(vbase + (int64_t)lane * 8 + i * 512);   // 1 KiB, contiguous
         }
+    };
+    // Load order (vector loads return in issue order): the new token's fp32 q/k/v row + cos/sin FIRST (a dozen small loads),
+    // the round's K/V stream right behind them with no wait in between, THEN the RoPE arithmetic — it waits for the row only
+    // (counted vmcnt) and runs, like the first QK^T MFMAs after it, while the K/V tiles are still arriving.  Round 2 waited
+    // for the row with vmcnt(0) before issuing the first K load; the first round-3 order (K/V first, row behind) made the
+    // RoPE and every MFMA wait for the whole K/V transfer (in-kernel stamps, scripts/decode_timeline.py: 2.3 us of compute
+    // after 6 us of transfer, nothing overlapped).  hd 128 keeps the row behind the K/V stream: 26 more live registers
+    // would spill.
+    constexpr bool ROW_FIRST = FUSED && HD == 64;
+    RopeRaw rq[KS / 2], rk[KS / 2];
+    f32x4 v0, v1;
+    const float* cs = nullptr;
+    if (ROW_FIRST) {
+        const float* row = p.qkv + (int64_t)tok * p.qkv_stride;
+        cs = p.cos_t ? p.cos_t + (int64_t)pos0 * HD : nullptr;
+        const float* sn = p.sin_t ? p.sin_t + (int64_t)pos0 * HD : nullptr;
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ks++) {
+            rope_load8(row + head * HD, cs, sn, ks * 32 + fg * 8, HALF, rq[ks]);
+            rope_load8(row + (p.nH + kvh) * HD, nullptr, nullptr, ks * 32 + fg * 8, HALF, rk[ks]);     // (cos / sin: the query's copy)
+        }
+        const float* vrow = row + (p.nH + p.nKV + kvh) * HD + dch * 8;
+        v0 = *(const f32x4*)vrow; v1 = *(const f32x4*)(vrow + 4);
+    }
+    if (vw < n_kt) issue_round(vw);
+    stamps.mark(1);                     // first round's K/V loads issued
+    if (ROW_FIRST) {
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ks++) {
+            rk[ks].c0 = rq[ks].c0; rk[ks].c1 = rq[ks].c1; rk[ks].s0 = rq[ks].s0; rk[ks].s1 = rq[ks].s1;
+            rope_math8(rq[ks], cs != nullptr, qf[ks], qf[ks + KS / 2]);
+            rope_math8(rk[ks], cs != nullptr, knew[ks], knew[ks + KS / 2]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) { vnew8[e] = (bf16_t)v0[e]; vnew8[4 + e] = (bf16_t)v1[e]; }
+    } else if (FUSED) {
+        const float* row = p.qkv + (int64_t)tok * p.qkv_stride;
+        const float* cs2 = p.cos_t ? p.cos_t + (int64_t)pos0 * HD : nullptr;
+        const float* sn = p.sin_t ? p.sin_t + (int64_t)pos0 * HD : nullptr;
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ks++) {
+            rope_pair8(row + head * HD, cs2, sn, ks * 32 + fg * 8, HALF, qf[ks], qf[ks + KS / 2]);
+            rope_pair8(row + (p.nH + kvh) * HD, cs2, sn, ks * 32 + fg * 8, HALF, knew[ks], knew[ks + KS / 2]);
+        }
+        const float* vrow = row + (p.nH + p.nKV + kvh) * HD + dch * 8;
+        const f32x4 w0 = *(const f32x4*)vrow, w1 = *(const f32x4*)(vrow + 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { vnew8[e] = (bf16_t)w0[e]; vnew8[4 + e] = (bf16_t)w1[e]; }
+    } else {
+        const bf16_t* qp = (const bf16_t*)p.q + (int64_t)tok * p.q_stride + head * HD;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) qf[ks] = *(const bf16x8*)(qp + ks * 32 + fg * 8);
+    }
+    stamps.mark(2);                     // q/k/v of the new token rotated
+    for (int kt0 = vw; kt0 < n_kt; kt0 += NT2 * nvw) {
+        if (kt0 != vw) issue_round(kt0);
         // ---- scores of the round's tiles ----
         f32x4 s[NT2][4];
         float tmax = -INFINITY;
@@ -601,6 +680,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
             *(bf16x8*)((bf16_t*)p.vcache + noff + dch * 8) = vnew8;
     }
     // ---- flash-decoding combine through LDS (the partial O^T overwrites this wave's own V image), fixed wave order ----
+    asm volatile("" :: "v"(o[0]));
+    stamps.mark(3);                     // wave 0's tiles done
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     if (fg == 0) { red_m[wave][fq] = m_run; red_l[wave][fq] = l_run; }
@@ -608,6 +689,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnArgs p) {
 #pragma unroll
     for (int d = 0; d < DT; d++) my_o[d * 64 + lane] = o[d];
     __syncthreads();
+    stamps.mark(4);                     // every wave's tiles done
     if (wave != 0 || !row_ok) return;
     float mstar = red_m[0][fq];
 #pragma unroll

@@ -81,6 +81,52 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- in-kernel time stamps (diagnostic runs only: nvl_set_debug mode 4) ------------------------------------------
+// A launch whose argument block carries a stamp buffer writes, per workgroup, the 100 MHz constant clock
+// (s_memrealtime: one counter for the whole chip) at up to 8 points of its life: scripts/decode_timeline.py turns a decode
+// step's stamps into dispatch spread / prologue / first data / stream / reduce / epilogue / gap to the next kernel.
+// Production launches pass a null pointer: one scalar branch per stamp site, nothing else.
+// The times are kept in registers and written when the object dies (the kernel's exits): a store to global memory at the
+// top of a kernel would make every later uniform load a vector load (the compiler may no longer assume the loaded
+// memory unclobbered, so it cannot use the scalar cache) — the instrumentation would change what it measures.
+struct NvlStamps {
+    unsigned long long* buf; int wg; unsigned long long t[6];
+    __device__ __forceinline__ NvlStamps(unsigned long long* b, int w) : buf(b), wg(w) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) t[i] = 0;
+        mark(0);
+    }
+    // (inline asm WITHOUT a memory clobber, fenced for the scheduler only: the builtin counts as a write to unknown memory,
+    //  after which the compiler turns every uniform load of the kernel into a vector load — in production builds too)
+    __device__ __forceinline__ void mark(int slot) {
+        if (buf) {
+            unsigned long long v;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v));
+            __builtin_amdgcn_sched_barrier(0);
+            t[slot] = v;
+        }
+    }
+    __device__ __forceinline__ ~NvlStamps() {
+        if (!buf) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores are retired
+        mark(5);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) buf[(size_t)wg * 8 + i] = t[i];
+        }
+    }
+};
+// compile-time switch for kernels with uniform global loads (decode attention): even a disabled stamp site is an opaque
+// side effect to the compiler, after which uniform loads may no longer use the scalar path
+template <bool ON> struct NvlStampsT;
+template <> struct NvlStampsT<true> : NvlStamps { using NvlStamps::NvlStamps; };
+template <> struct NvlStampsT<false> {
+    __device__ __forceinline__ NvlStampsT(unsigned long long*, int) {}
+    __device__ __forceinline__ void mark(int) {}
+};
+constexpr int STAMP_MAX_WG = 2048, STAMP_MAX_LAUNCH = 128;
+
 // ---- host error plumbing -------------------------------------------------------
 struct HipError {
     hipError_t code;

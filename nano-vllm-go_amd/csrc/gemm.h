@@ -93,6 +93,9 @@ struct GemmArgs {
     int m_passes;           // decode kernels, 64 < M: the launch covers m_passes = ceil(M/64) groups of 64 activation rows;
                             // the workgroups of one weight tile sit 8 block ids apart — same XCD, dispatched together —
                             // so the weights cross HBM once and the later groups hit L2 (see launch_gemm_bf16)
+    int grid_y;             // decode kernels: gridDim.y of the launch (set by the launcher)
+    unsigned long long* stamps;   // diagnostic runs: per-workgroup time stamps (common.h nvl_stamp), else NULL
+    int rs_half;            // producer, M <= 16: 8 weight rows per workgroup, x^2 partials per 8 columns (rs_tiles = N / 8)
     const float* nrm_w;     // producer: weight of the norm that follows, [N]
     bf16_t* nrm_xn;         // producer: xn_raw [M_pad16][N] fragment-major
     float* rs_out;          // producer: [64 rows][N/16]
@@ -623,10 +626,18 @@ __device__ __forceinline__ void skinny_pass_remap(GemmArgs& p, int& bx) {
     }
 }
 
-template <int MT, int NTW, int U, int EPI, typename OutT, bool PASSES = false, bool MOE = false>
+// HALF (deferred-norm residual projections of <= 16 rows: O and FFN-down at decode batches 1..16): a workgroup owns 8 of
+// a weight tile's 16 rows, so a 2048-column projection runs on 256 workgroups instead of 128 (x must be complete when the
+// launch ends — no K split over workgroups —, and with one workgroup per 16-row tile half of the CUs stayed idle while the
+// others pulled 256 KB each through one CU).  The other 8 lanes of every 16-lane row group feed zeros (their loads are
+// predicated off: 4 x 128-byte lines per k-step instead of 8); only the owned rows are stored; the x^2 partials are per
+// 8 columns (rs_tiles = N / 8).
+template <int MT, int NTW, int U, int EPI, typename OutT, bool PASSES = false, bool MOE = false, bool HALF = false>
 __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* red = (f32x4*)smem;                       // [NTW][ksplit][MT][64]
+    const int swg = blockIdx.y * gridDim.x + blockIdx.x;
+    NvlStamps stamps(p.stamps, swg);                 // (diagnostic runs; slot 0: workgroup entered)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ksplit = (blockDim.x >> 6) / NTW;
     const int tile = wave / ksplit, kw = wave - tile * ksplit;
@@ -634,15 +645,16 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     int bx = blockIdx.x;
     if constexpr (PASSES) skinny_pass_remap(p, bx);     // (its own instantiation: rewriting the arguments costs the
                                                         // single-group kernels a few scratch dwords otherwise)
+    const int half = HALF ? (bx & 1) : 0;
+    if constexpr (HALF) bx >>= 1;
+    const bool w_live = !HALF || (fr >> 3) == half;  // HALF: this lane's weight row belongs to the workgroup
     const int nt0 = bx * NTW;                        // first 16-row weight tile of this workgroup
     // K/32 k-steps dealt over (gridDim.y slices) x (ksplit waves) as evenly as possible (K need not divide:
     // Falcon's 4544 = 142 steps)
     const int i_off = p.m_split ? blockIdx.y : 0;                  // first 16-row activation tile of this workgroup
-    // deferred RMSNorm (consumer side): the scale of the rows of this wave's first epilogue element, fetched under the
-    // weight stream instead of after it
-    const int i_pre = wave % MT;
-    const float rstd_pre = ((EPI == EPI_STORE || EPI == EPI_SWIGLU) && wave < NTW * MT) ? deferred_rstd(p, 16 * i_pre + fr) : 1.0f;   // (only the waves that run an epilogue element)
-    const int nslices = p.m_split ? 1 : gridDim.y, slice = p.m_split ? 0 : blockIdx.y;
+    // (grid_y: gridDim.y as an explicit argument — the built-in lives in the hidden part of the kernarg block and costs a
+    // dependent scalar round trip of its own before the first weight load)
+    const int nslices = p.m_split ? 1 : p.grid_y, slice = p.m_split ? 0 : blockIdx.y;
     const int nparts = ksplit * nslices, part = slice * ksplit + kw;
     const int nks = p.K >> 5, q = nks / nparts, rr = nks - q * nparts;
     int my_steps = q + (part < rr ? 1 : 0);
@@ -675,7 +687,8 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     auto load_blk = [&](bf16x8 (&w)[U], bf16x8 (&x)[U][MT], int b) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            w[u] = weight_load<PASSES>((const bf16x8*)(wp + (int64_t)(b * U + u) * 512));
+            if constexpr (HALF) w[u] = w_live ? weight_load<PASSES>((const bf16x8*)(wp + (int64_t)(b * U + u) * 512)) : x_zero;
+            else w[u] = weight_load<PASSES>((const bf16x8*)(wp + (int64_t)(b * U + u) * 512));
 #pragma unroll
             for (int i = 0; i < MT; i++) {
                 const bf16x8* src = (const bf16x8*)(xp[i] + (int64_t)(b * U + u) * 512);
@@ -691,24 +704,32 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u], x[u][i], acc[i], 0, 0, 0);
     };
     if (nblk > 0) load_blk(wA, xA, 0);
+    stamps.mark(1);                     // first block of loads issued
+    // deferred RMSNorm (consumer side): the scale of the rows of this wave's first epilogue element.  Its loads are issued
+    // HERE, behind the first block of the weight stream (round 2 had them at the top of the kernel, where the compiler put
+    // their wait — a whole memory round trip, the partial sums were written by the previous kernel — and then a second
+    // kernarg batch in front of the first weight load).
+    const int i_pre = wave % MT;
+    const float rstd_pre = ((EPI == EPI_STORE || EPI == EPI_SWIGLU) && wave < NTW * MT) ? deferred_rstd(p, 16 * i_pre + fr) : 1.0f;   // (only the waves that run an epilogue element)
     // the residual operand of this wave's first epilogue element (deferred-norm producer form): fetched under the weight
     // stream, not as a dependent round trip after the K reduction (this launch is the only writer of these elements)
     f32x4 x_pre = f32x4{0.f, 0.f, 0.f, 0.f};
     if (EPI == EPI_RESID && !MOE && p.rs_out && wave < NTW * MT) {
         const int t = wave / MT, i = wave - t * MT;
         const int m = 16 * (i + i_off) + fr, n = (nt0 + t) * 16 + 4 * fg;
-        if (m < p.M && n < p.N) x_pre = *(const f32x4*)((const float*)p.C + (int64_t)m * p.ldc + n);
+        if (m < p.M && n < p.N && (!HALF || (fg >> 1) == half)) x_pre = *(const f32x4*)((const float*)p.C + (int64_t)m * p.ldc + n);
     }
     int b = 0;
     for (; b + 2 <= nblk; b += 2) {
         load_blk(wB, xB, b + 1);
         comp_blk(wA, xA);
+        if (b == 0) { asm volatile("" :: "v"(acc[0])); stamps.mark(2); }   // first block's data arrived and was used
         if (b + 2 < nblk) load_blk(wA, xA, b + 2);
         comp_blk(wB, xB);
     }
     if (b < nblk) comp_blk(wA, xA);
     for (int s = nblk * U; s < my_steps; s++) {      // ragged tail: fewer than U k-steps
-        const bf16x8 w = weight_load<PASSES>((const bf16x8*)(wp + (int64_t)s * 512));
+        const bf16x8 w = w_live ? weight_load<PASSES>((const bf16x8*)(wp + (int64_t)s * 512)) : x_zero;
 #pragma unroll
         for (int i = 0; i < MT; i++)
             acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x_live[i] ? *(const bf16x8*)(xp[i] + (int64_t)s * 512) : x_zero, acc[i], 0, 0, 0);
@@ -717,7 +738,9 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     // ---- reduce the K slices in wave order ----
 #pragma unroll
     for (int i = 0; i < MT; i++) red[((tile * ksplit + kw) * MT + i) * 64 + lane] = acc[i];
+    stamps.mark(3);                     // wave 0's stream done
     __syncthreads();
+    stamps.mark(4);                     // every wave's stream done
     auto ksum = [&](int t, int i) {
         f32x4 s = red[((t * ksplit) * MT + i) * 64 + lane];
         for (int w = 1; w < ksplit; w++) s += red[((t * ksplit + w) * MT + i) * 64 + lane];
@@ -747,7 +770,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
             const int m = 16 * (i + i_off) + fr, n = (nt0 + t) * 16 + 4 * fg;      // N % 16 == 0 (hidden width)
             f32x4 v = ksum(t, i);
             float ss = 0.f;
-            if (m < p.M && n < p.N) {
+            if (m < p.M && n < p.N && (!HALF || (fg >> 1) == half)) {
                 if (p.bias) v += *(const f32x4*)(p.bias + n);
                 float* x = (float*)p.C + (int64_t)m * p.ldc + n;
                 const f32x4 o = (e == wave ? x_pre : *(f32x4*)x) + p.alpha * v;
@@ -756,6 +779,10 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
                 ss = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
             }
             ss += __shfl_xor(ss, 16, 64);
+            if constexpr (HALF) {     // the two lane rows (fg = 2 half, 2 half + 1) of this workgroup's 8 columns
+                if (fg == 2 * half && (nt0 + t) * 16 < p.N) p.rs_out[(int64_t)m * (p.N >> 3) + 2 * (nt0 + t) + half] = ss;
+                continue;
+            }
             ss += __shfl_xor(ss, 32, 64);
             if (fg == 0 && (nt0 + t) * 16 < p.N) p.rs_out[(int64_t)m * (p.N >> 4) + (nt0 + t)] = ss;
         }
@@ -851,6 +878,8 @@ template <int MT, int NTB, int U, int EPI, typename OutT, bool PASSES = false, b
 __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* red = (f32x4*)smem;                       // [ksplit][NTB][MT][64]
+    const int swg = blockIdx.x;
+    NvlStamps stamps(p.stamps, swg);
     const int tid = threadIdx.x, lane = tid & 63, kw = tid >> 6;
     const int ksplit = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -863,10 +892,6 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
     const int my_steps = q + (kw < rr ? 1 : 0);
     const int ks0 = kw * q + (kw < rr ? kw : rr);
     const int64_t tile_stride = (int64_t)nks * 512;  // elements between consecutive 16-row weight tiles
-    // deferred RMSNorm: the scale of the rows this wave's epilogue elements belong to, fetched under the weight stream
-    const int i_pre = kw % MT;
-    const float rstd_pre = (EPI == EPI_SWIGLU || EPI == EPI_STORE) ? deferred_rstd(p, 16 * i_pre + fr) : 1.0f;
-
     const bf16_t* wp = (const bf16_t*)p.W + (((int64_t)nt0 * nks + ks0) * 64 + lane) * 8;
     const bf16_t* xp = (const bf16_t*)p.A + ((int64_t)ks0 * 64 + lane) * 8;
     f32x4 acc[NTB][MT];
@@ -899,10 +924,16 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
                     acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][t], x[u][i], acc[t][i], 0, 0, 0);
     };
     if (nblk > 0) load_blk(wA, xA, 0);
+    stamps.mark(1);
+    // deferred RMSNorm: the scale of the rows this wave's epilogue elements belong to; its loads go out behind the first
+    // block of the weight stream (not in front of it: see the narrow kernel)
+    const int i_pre = kw % MT;
+    const float rstd_pre = (EPI == EPI_SWIGLU || EPI == EPI_STORE) ? deferred_rstd(p, 16 * i_pre + fr) : 1.0f;
     int b = 0;
     for (; b + 2 <= nblk; b += 2) {
         load_blk(wB, xB, b + 1);
         comp_blk(wA, xA);
+        if (b == 0) { asm volatile("" :: "v"(acc[0][0])); stamps.mark(2); }
         if (b + 2 < nblk) load_blk(wA, xA, b + 2);
         comp_blk(wB, xB);
     }
@@ -923,7 +954,9 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
     for (int t = 0; t < NTB; t++)
 #pragma unroll
         for (int i = 0; i < MT; i++) red[((kw * NTB + t) * MT + i) * 64 + lane] = acc[t][i];
+    stamps.mark(3);
     __syncthreads();
+    stamps.mark(4);
     auto ksum = [&](int t, int i) {
         f32x4 s = red[(t * MT + i) * 64 + lane];
         for (int w = 1; w < ksplit; w++) s += red[((w * NTB + t) * MT + i) * 64 + lane];
@@ -990,6 +1023,9 @@ static inline bool launch_skinny_passes_serial(hipStream_t st, const GemmArgs& a
 template <int NTW, int EPI, typename OutT>
 static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
     const int MT = skinny_rows(a) <= 16 ? 1 : (skinny_rows(a) <= 32 ? 2 : 4);
+    if (EPI == EPI_RESID && a.m_split && a.rs_out && NTW == 1 && a.m_passes <= 1 && a.grid_y != 1) {   // (m_split: grid_y unused, keep it defined)
+        GemmArgs c = a; c.grid_y = 1; return launch_gemm_skinny_ntw<NTW, EPI, OutT>(st, c);
+    }
     const int U = MT <= 2 ? 4 : 2;                       // register budget: (1+MT)*U*2 fragments
     const int nblocks = cdiv(cdiv(a.N, 16), NTW);        // weight rows are padded to 128: all tiles exist
     const int KS = (EPI == EPI_RESID && a.sk_part && a.sk_slices > 1) ? a.sk_slices : 1;
@@ -998,6 +1034,14 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
         int ks = g_msplit_ks;
         while (ks > 1 && (a.K >> 5) / ks < 4) ks >>= 1;
         if (a.K % 32 != 0) return false;
+        if constexpr (EPI == EPI_RESID) {
+            if (a.rs_half) {      // <= 16 rows: 8 weight rows per workgroup, twice the workgroups (HALF above)
+                if (a.M > 16) return false;
+                hipLaunchKernelGGL((gemm_skinny_bf16_kernel<1, NTW, 4, EPI, OutT, false, false, true>), dim3(2 * nblocks, 1), dim3(NTW * ks * 64),
+                                   (size_t)NTW * ks * 64 * 16, st, a);
+                return true;
+            }
+        }
         hipLaunchKernelGGL((gemm_skinny_bf16_kernel<1, NTW, 4, EPI, OutT>), dim3(nblocks, cdiv(a.M, 16)), dim3(NTW * ks * 64),
                            (size_t)NTW * ks * 64 * 16, st, a);
         return true;
@@ -1016,6 +1060,7 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
     const size_t lds = (size_t)NTW * ksplit * MT * 64 * 16;
     if (a.m_passes > 1 && (nblocks % 8 != 0 || KS != 1)) return launch_skinny_passes_serial<EPI, OutT>(st, a);
     dim3 grid(nblocks * (a.m_passes > 1 ? a.m_passes : 1), KS), block(NTW * ksplit * 64);
+    if (a.grid_y != KS) { GemmArgs c = a; c.grid_y = KS; return launch_gemm_skinny_ntw<NTW, EPI, OutT>(st, c); }
 #define NVL_SK(MTv, Uv) hipLaunchKernelGGL((gemm_skinny_bf16_kernel<MTv, NTW, Uv, EPI, OutT>), grid, block, lds, st, a)
 #define NVL_SKM(MTv, Uv) hipLaunchKernelGGL((gemm_skinny_bf16_kernel<MTv, NTW, Uv, EPI, OutT, false, true>), grid, block, lds, st, a)
     if constexpr (EPI == EPI_SWIGLU || EPI == EPI_RESID) {

@@ -159,6 +159,10 @@ struct nvl_model {
     bool graphs_ok = true;
     int32_t* am_host = nullptr;                       // pinned: argmax ids of a replayed decode pass
     // debug
+    // nvl_set_debug mode 4: in-kernel time stamps of the decode kernels (common.h nvl_stamp), one record per launch
+    bool stamping = false; unsigned long long* stamp_buf = nullptr; int stamp_launches = 0;
+    struct StampRec { int site, phase, nwg; };
+    std::vector<StampRec> stamp_recs;
     bool tap = false;            // nvl_set_debug mode 2: record every layer's residual stream without leaving the product path
     bool keep_hidden = false; float* hidden = nullptr; int64_t hidden_tokens = 0; int hidden_last_M = 0;
     // stats

@@ -144,7 +144,14 @@ void drain_profile(nvl_model* m) {
 
 // ---- GEMM dispatch ---------------------------------------------------------------------------
 // out_f32: output element type of STORE (fp32 vs activation type)
+// diagnostic runs (nvl_set_debug mode 4): the stamp slab of the next launch, or NULL
+unsigned long long* next_stamps(nvl_model* m, int site, int nwg) {
+    if (!m->stamping || !m->stamp_buf || m->stamp_launches >= STAMP_MAX_LAUNCH || nwg > STAMP_MAX_WG) return nullptr;
+    m->stamp_recs.push_back({site, m->phase, nwg});
+    return m->stamp_buf + (size_t)(m->stamp_launches++) * STAMP_MAX_WG * 8;
+}
 void gemm(nvl_model* m, int epi, bool out_f32, GemmArgs a, double flops = -1.0) {
+    a.stamps = (m->stamping && !m->f32 && a.M <= 64 && !a.tile_map) ? next_stamps(m, m->site, STAMP_MAX_WG) : nullptr;
     // algorithmic bytes of a projection: every weight byte once + the activation operand + the output rows
     const double gbytes = m->site_bytes > 0 ? m->site_bytes
         : ((double)a.N * a.K + (double)a.M * a.K) * (double)m->wsize + (double)a.M * a.N * (out_f32 || epi == EPI_RESID ? 4.0 : (double)m->wsize);
@@ -329,7 +336,7 @@ extern "C" void nvl_destroy(nvl_model* m) {
     clear_graphs(m);
     if (m->am_host) (void)hipHostFree(m->am_host);
     dfree(m->ring_pos0);
-    dfree(m->conv_tail);
+    dfree(m->conv_tail); dfree(m->stamp_buf);
     dfree(m->ssm_state); dfree(m->mproj); dfree(m->mxbc); dfree(m->mdelta); dfree(m->my); dfree(m->myn);
     free_sample_bufs(m->samp);
     dfree(m->samp_hist); dfree(m->samp_hist_len); dfree(m->samp_u_steps);
@@ -824,7 +831,7 @@ extern "C" int nvl_finalize(nvl_model* m) {
     // split-K partial slices of the residual projections: decode (<= 64 rows) and mid-size batches (<= SK_TILE_MAX_M rows)
     m->sk_rows = (int)std::min<int64_t>(std::max<int64_t>(Mmax, 64), SK_TILE_MAX_M);
     if (!m->f32) m->sk_part = dmalloc<float>((int64_t)std::max(m->sk_max_slices, SK_TILE_MAX_SLICES) * m->sk_rows * H);
-    if (!m->f32) m->rs_part = dmalloc<float>((int64_t)cdiv(H, 16) * DEFER_MAX_M);
+    if (!m->f32) m->rs_part = dmalloc<float>((int64_t)cdiv(H, 8) * DEFER_MAX_M);      // x^2 partials per 16 (half tiles: 8) columns
     if (m->tp > 1 || m->tp_force) m->tp_part = dmalloc<float>(Mmax * H);
     m->meta_ints = 3 * Mmax + 5 * S + m->table_cap + 16;
     NVL_HIP(hipHostMalloc((void**)&m->meta_host, (size_t)m->meta_ints * 4, hipHostMallocDefault));
@@ -1113,22 +1120,33 @@ void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, do
         // fills the chip (>= 2 workgroups per CU) fewer, longer-running waves stream better than many short ones
         // (profiles/r01g_decode_attention_waves.txt).  ctx_hint = the batch's longest context when the caller knows it.
         const int nw = cfg & 255;
+        a.stamps = (fused_qkv && m->hd == 64) ? next_stamps(m, KS_ATTN, (int)(grid.x * grid.y * grid.z)) : nullptr;
         if (fused_qkv) {   // RoPE + KV append + attention in one launch, straight from the QKV projection's fp32 output
             a.qkv = m->qkv; a.qkv_stride = m->n_qkv; a.cos_t = m->rope_cos; a.sin_t = m->rope_sin;
         }
+#define NVL_DEC_LEAD a.seq_pos, a.blk_table, a.tbl_stride, a.bs_shift, a.Tmax, a.group      /* the preloaded leading arguments (attn.h) */
 #define NVL_DEC(HDv, FUSEDv)                                                                                           \
         do {                                                                                                           \
             constexpr int tile_bytes = 64 * HDv * 2;                                                                   \
-            if (nw == 2) hipLaunchKernelGGL((attn_decode_bf16_kernel<HDv, 2, FUSEDv>), grid, dim3(128), 2 * tile_bytes, m->stream, a);      \
-            else if (nw == 4) hipLaunchKernelGGL((attn_decode_bf16_kernel<HDv, 4, FUSEDv>), grid, dim3(256), 4 * tile_bytes, m->stream, a); \
+            if (nw == 2) hipLaunchKernelGGL((attn_decode_bf16_kernel<HDv, 2, FUSEDv>), grid, dim3(128), 2 * tile_bytes, m->stream, NVL_DEC_LEAD, a);      \
+            else if (nw == 4) hipLaunchKernelGGL((attn_decode_bf16_kernel<HDv, 4, FUSEDv>), grid, dim3(256), 4 * tile_bytes, m->stream, NVL_DEC_LEAD, a); \
             else {                                                                                                     \
                 NVL_LDS_ATTR((attn_decode_bf16_kernel<HDv, 8, FUSEDv>), 8 * tile_bytes);                               \
-                hipLaunchKernelGGL((attn_decode_bf16_kernel<HDv, 8, FUSEDv>), grid, dim3(512), 8 * tile_bytes, m->stream, a);               \
+                hipLaunchKernelGGL((attn_decode_bf16_kernel<HDv, 8, FUSEDv>), grid, dim3(512), 8 * tile_bytes, m->stream, NVL_DEC_LEAD, a);               \
             }                                                                                                          \
         } while (0)
-        if (fused_qkv) { if (m->hd == 64) NVL_DEC(64, true); else NVL_DEC(128, true); }
+        if (a.stamps && fused_qkv && m->hd == 64) {     // diagnostic instantiation with the in-kernel stamps compiled in
+            constexpr int tb = 64 * 64 * 2;
+            if (nw == 2) hipLaunchKernelGGL((attn_decode_bf16_kernel<64, 2, true, true>), grid, dim3(128), 2 * tb, m->stream, NVL_DEC_LEAD, a);
+            else if (nw == 4) hipLaunchKernelGGL((attn_decode_bf16_kernel<64, 4, true, true>), grid, dim3(256), 4 * tb, m->stream, NVL_DEC_LEAD, a);
+            else {
+                NVL_LDS_ATTR((attn_decode_bf16_kernel<64, 8, true, true>), 8 * tb);
+                hipLaunchKernelGGL((attn_decode_bf16_kernel<64, 8, true, true>), grid, dim3(512), 8 * tb, m->stream, NVL_DEC_LEAD, a);
+            }
+        } else if (fused_qkv) { if (m->hd == 64) NVL_DEC(64, true); else NVL_DEC(128, true); }
         else { if (m->hd == 64) NVL_DEC(64, false); else NVL_DEC(128, false); }
 #undef NVL_DEC
+#undef NVL_DEC_LEAD
     } else {
         // 256 query rows (position x head-in-group, position-major) per workgroup of 8 waves; K/V tiles by LDS-DMA
         const int64_t qrows = (int64_t)max_len * m->group;
@@ -1174,7 +1192,7 @@ GemmArgs mk(const void* A, int lda, const void* W, void* C, int ldc, const float
     a.M = M; a.N = N; a.K = K; a.seg = nullptr; a.c_row0 = 0;
     a.qkv = QkvEpi{};
     a.tile_map = nullptr; a.n_mtiles = nullptr; a.w_expert_stride = 0;
-    a.sk_part = nullptr; a.sk_slices = 1; a.m_split = 0; a.nrm_w = nullptr; a.nrm_xn = nullptr; a.rs_out = nullptr; a.rs_in = nullptr; a.rs_tiles = 0; a.rs_inv_h = 0.f; a.rs_eps = 0.f;
+    a.sk_part = nullptr; a.sk_slices = 1; a.m_split = 0; a.rs_half = 0; a.grid_y = 1; a.nrm_w = nullptr; a.nrm_xn = nullptr; a.rs_out = nullptr; a.rs_in = nullptr; a.rs_tiles = 0; a.rs_inv_h = 0.f; a.rs_eps = 0.f;
     return a;
 }
 
@@ -1275,8 +1293,11 @@ static int g_decode_seam = 1;  // nvl_set_tuning key 7: decode_seam_kernel in nv
 static int g_defer_norm = 1;   // nvl_set_tuning key 3: deferred RMSNorm between O-proj and FFN-up in decode (0 = off)
 static int g_sk_slices = 0;    // tuning override (nvl_set_tuning key 1): 0 automatic, 1 = never split
 // consumer side of the deferred RMSNorm: the projection reads xn_raw and scales its accumulators (gemm.h)
+static int g_half_tiles = 1;   // nvl_set_tuning key 27: deferred-norm residual projections of <= 16 rows on 8-row half tiles (gemm.h HALF)
+// (producer and consumer agree through M alone: every projection of a pass has the same row count)
+bool defer_half(const nvl_model* m, int M) { return g_half_tiles && M <= 16 && m->H % 128 == 0; }
 void set_deferred_in(nvl_model* m, GemmArgs& a) {
-    a.rs_in = m->rs_part; a.rs_tiles = m->H / 16; a.rs_inv_h = 1.0f / (float)m->H; a.rs_eps = m->cfg.norm_eps;
+    a.rs_in = m->rs_part; a.rs_tiles = defer_half(m, a.M) ? m->H / 8 : m->H / 16; a.rs_inv_h = 1.0f / (float)m->H; a.rs_eps = m->cfg.norm_eps;
 }
 void resid_gemm(nvl_model* m, const void* A, int lda, const void* W, const float* bias, float alpha, int M, int N, int K,
                 const float* defer_norm_w = nullptr) {
@@ -1299,6 +1320,7 @@ void resid_gemm(nvl_model* m, const void* A, int lda, const void* W, const float
     GemmArgs a = mk(A, lda, W, m->x, N, bias, alpha, M, N, K);
     if (defer_norm_w) {     // deferred RMSNorm: x complete in this launch (no K split over workgroups) + xn_raw + x^2 partials
         a.nrm_w = defer_norm_w; a.nrm_xn = (bf16_t*)m->xn; a.rs_out = m->rs_part; a.m_split = g_defer_norm >= 2 ? 0 : 1;
+        a.rs_half = a.m_split && N == m->H && defer_half(m, M) ? 1 : 0;
         gemm(m, EPI_RESID, true, a);
         return;
     }
@@ -1488,7 +1510,7 @@ namespace {
 // of a key runs eagerly (it also sets the per-function attributes, which must not happen during capture).
 template <typename F>
 bool replay_or_capture(nvl_model* m, const std::array<int, 5>& key, F&& enqueue) {
-    if (!g_use_graphs || !m->graphs_ok || m->profile || m->keep_hidden || m->tap || m->tp > 1 || m->tp_force) return false;
+    if (!g_use_graphs || !m->graphs_ok || m->profile || m->keep_hidden || m->tap || m->stamping || m->tp > 1 || m->tp_force) return false;
     auto it = m->graphs.find(key);
     if (it != m->graphs.end()) { NVL_HIP(hipGraphLaunch(it->second, m->stream)); m->stats.graph_replays++; return true; }
     if (!m->graph_seen.count(key)) { m->graph_seen.insert(key); return false; }
@@ -2234,7 +2256,37 @@ extern "C" int nvl_set_debug(nvl_model* m, int keep_hidden) {
     if (!m) return NVL_ERR_INVALID;
     m->keep_hidden = keep_hidden == 1;      // 1: per-layer residual stream, every residual add completed in its own launch
     m->tap = keep_hidden == 2;              // 2: the same record taken beside the unmodified product path (pending adds included)
+    m->stamping = keep_hidden == 4;         // 4: in-kernel time stamps of the decode kernels (nvl_get_stamps), eager launches
+    if (m->stamping) {
+        NVL_TRY(m)
+        NVL_HIP(hipSetDevice(m->device));
+        if (!m->stamp_buf) m->stamp_buf = (unsigned long long*)dmalloc_bytes((int64_t)STAMP_MAX_LAUNCH * STAMP_MAX_WG * 8 * 8);
+        NVL_HIP(hipStreamSynchronize(m->stream));
+        NVL_HIP(hipMemset(m->stamp_buf, 0, (size_t)STAMP_MAX_LAUNCH * STAMP_MAX_WG * 8 * 8));
+        m->stamp_launches = 0; m->stamp_recs.clear();
+        NVL_CATCH(m)
+    }
     return NVL_OK;
+}
+// nvl_set_debug(m, 4) ... forward passes ... nvl_get_stamps: per stamped launch {site, phase, workgroups} in `recs`
+// (3 ints each) and its stamps [workgroups][8] of the 100 MHz clock back to back in `stamps`.  Returns the launch count.
+extern "C" int nvl_get_stamps(nvl_model* m, int32_t* recs, int rec_cap, uint64_t* stamps, int64_t stamp_cap) {
+    if (!m) return NVL_ERR_INVALID;
+    if (!m->stamp_buf) return fail(m, NVL_ERR_STATE, "nvl_get_stamps: nvl_set_debug(m, 4) first");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    NVL_HIP(hipStreamSynchronize(m->stream));
+    const int n = (int)m->stamp_recs.size();
+    int64_t off = 0;
+    for (int i = 0; i < n && i < rec_cap; i++) {
+        const auto& r = m->stamp_recs[(size_t)i];
+        recs[3 * i] = r.site; recs[3 * i + 1] = r.phase; recs[3 * i + 2] = r.nwg;
+        if (off + (int64_t)r.nwg * 8 > stamp_cap) return fail(m, NVL_ERR_INVALID, "nvl_get_stamps: stamp buffer too small");
+        NVL_HIP(hipMemcpy(stamps + off, m->stamp_buf + (size_t)i * STAMP_MAX_WG * 8, (size_t)r.nwg * 64, hipMemcpyDeviceToHost));
+        off += (int64_t)r.nwg * 8;
+    }
+    return n;
+    NVL_CATCH(m)
 }
 extern "C" int nvl_get_hidden(nvl_model* m, int layer, float* out, int64_t n_floats) {
     if (!m || !out) return NVL_ERR_INVALID;
