@@ -193,6 +193,10 @@ int nvl_tp_attach_local(nvl_model** models, int n);
  * when no peer buffers are attached. */
 int nvl_tp_p2p_export(nvl_model* m, void* handle_out, int bytes);                 /* bytes >= 64 */
 int nvl_tp_p2p_attach(nvl_model* m, const void* handles, int bytes_per_handle);   /* tp_size handles, rank order */
+/* A rank waits a bounded time for its peers inside an all-reduce (nvl_set_tuning key 29, milliseconds, default 30 000); when
+ * the wait gives up the forward call fails and the group stays unusable until EVERY rank has called nvl_tp_p2p_rearm while
+ * no rank is inside a forward call (collective in that sense). */
+int nvl_tp_p2p_rearm(nvl_model* m);
 
 /* ---- sequences: replace map[int64]*KVCache (tensor_model_runner.go:11-18,59-68,100-112) ---- */
 int nvl_seq_open(nvl_model* m, int64_t seq_id);     /* get-or-create a KV slot                     */
@@ -428,6 +432,8 @@ int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int 
  * key 26: residual projections of 65..2048 rows split K over up to 8 workgroups per 128x128 tile, the slices summed by the
  * norm that follows (1, default; 0 = the 64-row groups of the decode form / plain tiles).
  * key 24: the decode GEMM kernels do not fetch the activation rows >= M of a padded 16-row tile (1, default).
+ * key 27: deferred-norm residual projections of <= 16 rows run on 8-row half tiles, twice the workgroups (1, default).
+ * key 29: milliseconds a tensor-parallel rank waits for its peers inside a P2P all-reduce before the call fails (default 30000).
  * The settings are PROCESS-GLOBAL and unsynchronised (every model in the process sees them): set them from one thread
  * while no forward call is running.  Every call starts a new tuning epoch: captured decode graphs bake the tuning in and are re-captured.
  * Returns the previous value. */

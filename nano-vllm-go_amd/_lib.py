@@ -165,6 +165,7 @@ def lib():
     L.nvl_tp_attach_local.argtypes = [vp, C.c_int]
     L.nvl_tp_p2p_export.argtypes = [vp, vp, C.c_int]
     L.nvl_tp_p2p_attach.argtypes = [vp, vp, C.c_int]
+    L.nvl_tp_p2p_rearm.argtypes = [vp]
     L.nvl_sizeof.argtypes = [C.c_int]
     _lib = L
     return L

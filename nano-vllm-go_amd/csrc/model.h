@@ -86,7 +86,6 @@ struct nvl_model {
     float* tp_part = nullptr;         // [Mmax][H] fp32 partial of a row-parallel projection
     // hand-written all-reduce over peer-mapped buffers (tp_p2p.h): own comm buffer + the peers' (IPC-opened) ones
     char* p2p_buf = nullptr; size_t p2p_bytes = 0; char* p2p_peer[8] = {nullptr}; bool p2p_ready = false;
-    uint64_t p2p_calls = 0; unsigned long long p2p_expect[2][3] = {{0, 0, 0}, {0, 0, 0}};
     int64_t p2p_off_in1 = 0, p2p_off_in2 = 0, p2p_off_res = 0, p2p_in1_stride = 0, p2p_in2_stride = 0, p2p_res_stride = 0;
     int n_qkv = 0, Tmax = 0;     // Tmax: tokens per KV block (slab mode: the whole slot; paged: kv_block_size)
     int paged = 0, num_blocks = 0, blocks_per_seq = 1, table_cap = 0;   // KV addressing (see kv_locate)

@@ -876,8 +876,8 @@ void p2p_alloc(nvl_model* m) {
     const int64_t esz = m->f32 ? 4 : 2, T = m->tp;
     const int64_t cap = (int64_t)m->opts.max_batch_tokens * m->H;
     m->p2p_in1_stride = (int64_t)P2P_ONESHOT_CAP_ROWS * m->H;
-    m->p2p_in2_stride = round_up(cdiv(cap, T), 4);
-    m->p2p_res_stride = round_up(cap, 4);
+    m->p2p_in2_stride = round_up(cdiv(cap, T), 8);       // (16-byte peer stores: 8 bf16)
+    m->p2p_res_stride = round_up(cap, 8);
     m->p2p_off_in1 = 1024;
     m->p2p_off_in2 = round_up(m->p2p_off_in1 + 2 * T * m->p2p_in1_stride * esz, 256);
     m->p2p_off_res = round_up(m->p2p_off_in2 + 2 * T * m->p2p_in2_stride * esz, 256);
@@ -916,6 +916,21 @@ extern "C" int nvl_tp_p2p_attach(nvl_model* m, const void* handles, int bytes_pe
         m->p2p_peer[r] = (char*)p;
     }
     m->p2p_ready = true;
+    return NVL_OK;
+    NVL_CATCH(m)
+}
+
+// After a timed-out all-reduce (nvl_forward failed with "timed out waiting for a peer rank") the group's arrival counters are
+// out of step.  Every rank calls this while NO rank is inside a forward call (e.g. behind a host barrier): it zeroes the
+// rank's own header — arrival counters, call counters, error word — and drops the captured graphs.
+extern "C" int nvl_tp_p2p_rearm(nvl_model* m) {
+    if (!m) return NVL_ERR_INVALID;
+    if (!m->p2p_buf) return fail(m, NVL_ERR_STATE, "nvl_tp_p2p_rearm: no P2P group (nvl_tp_p2p_export / _attach first)");
+    NVL_TRY(m)
+    NVL_HIP(hipSetDevice(m->device));
+    NVL_HIP(hipStreamSynchronize(m->stream));
+    NVL_HIP(hipMemset(m->p2p_buf, 0, 1024));
+    NVL_HIP(hipDeviceSynchronize());
     return NVL_OK;
     NVL_CATCH(m)
 }
@@ -1237,45 +1252,40 @@ void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
     }
 }
 
+static int g_half_tiles = 1;   // nvl_set_tuning key 27: deferred-norm residual projections of <= 16 rows on 8-row half tiles (gemm.h HALF)
+// (producer and consumer agree through M alone: every projection of a pass has the same row count)
+bool defer_half(const nvl_model* m, int M) { return g_half_tiles && M <= 16 && m->H % 128 == 0; }
 // after a forward's stream sync: did a P2P wait give up?  (a peer died or never called: the residual stream is garbage)
 void p2p_check(nvl_model* m) {
     if (!m->p2p_ready) return;
     int err = 0;
-    NVL_HIP(hipMemcpy(&err, m->p2p_buf + 960, 4, hipMemcpyDeviceToHost));
-    if (err) throw std::runtime_error("tensor-parallel all-reduce: timed out waiting for a peer rank (the group is unusable)");
+    NVL_HIP(hipMemcpy(&err, m->p2p_buf + P2P_OFF_ERR, 4, hipMemcpyDeviceToHost));
+    if (err) throw std::runtime_error("tensor-parallel all-reduce: timed out waiting for a peer rank (nvl_tp_p2p_rearm on every rank clears the group)");
 }
-// x += alpha * sum over the tensor-parallel ranks of `part` [M][N], by direct peer stores over the xGMI mesh (tp_p2p.h)
-void tp_p2p_allreduce_resid(nvl_model* m, const float* part, int M, int N, float alpha) {
+static int g_p2p_spin_ms = 30000;     // nvl_set_tuning key 29: how long a rank waits for its peers inside an all-reduce before it gives up
+// x += alpha * sum over the tensor-parallel ranks of `part` [M][N], by direct peer stores over the xGMI mesh (tp_p2p.h): ONE
+// launch.  nrm_w != NULL (decode, RMSNorm + SwiGLU): the same launch emits the deferred-RMSNorm operand of the next projection.
+void tp_p2p_allreduce_resid(nvl_model* m, const float* part, int M, int N, float alpha, const float* nrm_w = nullptr) {
     const int64_t count = (int64_t)M * N;
-    if (count % 4) throw std::runtime_error("tp p2p: payload must be a multiple of 4 elements");
+    if (count % 8 || N % 16) throw std::runtime_error("tp p2p: the row length must be a multiple of 16");
     P2PArgs a{};
-    a.T = m->tp; a.rank = m->tp_rank; a.parity = (int)(m->p2p_calls & 1); m->p2p_calls++;
+    a.T = m->tp; a.rank = m->tp_rank;
     a.count = count; a.part = part; a.x = m->x; a.alpha = alpha;
     for (int r = 0; r < m->tp; r++) a.peer[r] = m->p2p_peer[r];
-    a.off_ctr = 0; a.off_err = 960; a.off_in1 = m->p2p_off_in1; a.off_in2 = m->p2p_off_in2; a.off_res = m->p2p_off_res;
+    a.off_in1 = m->p2p_off_in1; a.off_in2 = m->p2p_off_in2; a.off_res = m->p2p_off_res;
     a.in1_stride = m->p2p_in1_stride; a.in2_stride = m->p2p_in2_stride; a.res_stride = m->p2p_res_stride;
-    a.spin_limit = 3000000;                                   // x ~1 us of s_sleep: seconds, then the group is marked dead (off_err)
-    const int nwg = (int)std::min<int64_t>(cdiv(count, 1024), 512);
+    a.spin_limit = (int)std::min<int64_t>((int64_t)g_p2p_spin_ms * 1000, 2000000000);      // x ~1 us of s_sleep per poll
+    a.oneshot = (M <= g_p2p_oneshot_rows && M <= P2P_ONESHOT_CAP_ROWS) ? 1 : 0;
+    if (!a.oneshot) a.chunk = round_up(cdiv(count, a.T), 8);
+    if (nrm_w) {
+        if (!a.oneshot) throw std::runtime_error("tp p2p: the fused norm rides on the one-shot form");
+        a.H = N; a.nrm_w = nrm_w; a.nrm_xn = (bf16_t*)m->xn; a.rs_out = m->rs_part; a.rs_cols = defer_half(m, M) ? 8 : 16;
+    }
+    const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(count, 256 * 8), 512));    // all resident: the kernel spins
     KScope ks(m, KC_OTHER, 0, KS_ALLREDUCE, (double)count * (m->f32 ? 4.0 : 2.0) * 2.0);
-    const bool oneshot = M <= g_p2p_oneshot_rows && M <= P2P_ONESHOT_CAP_ROWS;
-#define NVL_P2P(PT)                                                                                                    \
-    do {                                                                                                               \
-        if (oneshot) {                                                                                                 \
-            hipLaunchKernelGGL((p2p_oneshot_send_kernel<PT>), dim3(nwg), dim3(256), 0, m->stream, a);                  \
-            a.target = (m->p2p_expect[a.parity][0] += (unsigned long long)a.T * nwg);                                  \
-            hipLaunchKernelGGL((p2p_oneshot_apply_kernel<PT>), dim3(nwg), dim3(256), 0, m->stream, a);                 \
-        } else {                                                                                                       \
-            a.chunk = round_up(cdiv(count, a.T), 4);                                                                   \
-            const int nwg2 = (int)std::min<int64_t>(cdiv(a.chunk, 1024), 512);                                         \
-            hipLaunchKernelGGL((p2p_rs_send_kernel<PT>), dim3(nwg), dim3(256), 0, m->stream, a);                       \
-            a.target = (m->p2p_expect[a.parity][1] += (unsigned long long)a.T * nwg);                                  \
-            hipLaunchKernelGGL((p2p_rs_reduce_bcast_kernel<PT>), dim3(nwg2), dim3(256), 0, m->stream, a);              \
-            a.target = (m->p2p_expect[a.parity][2] += (unsigned long long)a.T * nwg2);                                 \
-            hipLaunchKernelGGL((p2p_ag_apply_kernel<PT>), dim3(nwg), dim3(256), 0, m->stream, a);                      \
-        }                                                                                                              \
-    } while (0)
-    if (m->f32) NVL_P2P(float); else NVL_P2P(bf16_t);
-#undef NVL_P2P
+    if (m->f32) hipLaunchKernelGGL((p2p_allreduce_kernel<float, false>), dim3(nwg), dim3(256), 0, m->stream, a);
+    else if (nrm_w) hipLaunchKernelGGL((p2p_allreduce_kernel<bf16_t, true>), dim3(nwg), dim3(256), 0, m->stream, a);
+    else hipLaunchKernelGGL((p2p_allreduce_kernel<bf16_t, false>), dim3(nwg), dim3(256), 0, m->stream, a);
     NVL_HIP(hipGetLastError());
 }
 
@@ -1293,9 +1303,6 @@ static int g_decode_seam = 1;  // nvl_set_tuning key 7: decode_seam_kernel in nv
 static int g_defer_norm = 1;   // nvl_set_tuning key 3: deferred RMSNorm between O-proj and FFN-up in decode (0 = off)
 static int g_sk_slices = 0;    // tuning override (nvl_set_tuning key 1): 0 automatic, 1 = never split
 // consumer side of the deferred RMSNorm: the projection reads xn_raw and scales its accumulators (gemm.h)
-static int g_half_tiles = 1;   // nvl_set_tuning key 27: deferred-norm residual projections of <= 16 rows on 8-row half tiles (gemm.h HALF)
-// (producer and consumer agree through M alone: every projection of a pass has the same row count)
-bool defer_half(const nvl_model* m, int M) { return g_half_tiles && M <= 16 && m->H % 128 == 0; }
 void set_deferred_in(nvl_model* m, GemmArgs& a) {
     a.rs_in = m->rs_part; a.rs_tiles = defer_half(m, a.M) ? m->H / 8 : m->H / 16; a.rs_inv_h = 1.0f / (float)m->H; a.rs_eps = m->cfg.norm_eps;
 }
@@ -1305,7 +1312,8 @@ void resid_gemm(nvl_model* m, const void* A, int lda, const void* W, const float
         // row-parallel projection: this rank holds a K slice -> fp32 partial [M][N] (the bias lives on rank 0 only),
         // all-reduce over the tensor-parallel group, then the residual add (folded into the next norm for decode)
         gemm(m, EPI_STORE, true, mk(A, lda, W, m->tp_part, N, bias, 1.f, M, N, K));
-        if (m->p2p_ready) { tp_p2p_allreduce_resid(m, m->tp_part, M, N, alpha); return; }     // sum + residual add in one go
+        if (m->p2p_ready) { tp_p2p_allreduce_resid(m, m->tp_part, M, N, alpha, defer_norm_w); return; }     // sum + residual add (+ the deferred norm) in one go
+        if (defer_norm_w) throw std::runtime_error("resid_gemm: the deferred norm of a tensor-parallel projection needs the P2P all-reduce");
         tp_allreduce(m, m->tp_part, (int64_t)M * N);
         if (!m->f32 && M <= 64 && !m->keep_hidden && m->pending_slices == 0) {
             m->pending_part = m->tp_part; m->pending_slices = 1; m->pending_rows = M; m->pending_alpha = alpha;
@@ -1510,7 +1518,9 @@ namespace {
 // of a key runs eagerly (it also sets the per-function attributes, which must not happen during capture).
 template <typename F>
 bool replay_or_capture(nvl_model* m, const std::array<int, 5>& key, F&& enqueue) {
-    if (!g_use_graphs || !m->graphs_ok || m->profile || m->keep_hidden || m->tap || m->stamping || m->tp > 1 || m->tp_force) return false;
+    // (tensor parallel: only with the P2P all-reduce, whose call state lives on the device; RCCL / the in-process emulation
+    //  are host-driven)
+    if (!g_use_graphs || !m->graphs_ok || m->profile || m->keep_hidden || m->tap || m->stamping || ((m->tp > 1 || m->tp_force) && !m->p2p_ready)) return false;
     auto it = m->graphs.find(key);
     if (it != m->graphs.end()) { NVL_HIP(hipGraphLaunch(it->second, m->stream)); m->stats.graph_replays++; return true; }
     if (!m->graph_seen.count(key)) { m->graph_seen.insert(key); return false; }
@@ -1587,7 +1597,10 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
     // decode, RMSNorm + SwiGLU, sequential block: every residual projection carries the norm that follows it (deferred
     // RMSNorm, gemm.h), so a step keeps ONE norm launch (layer 0's, after the embedding) instead of 2L + 1
     const bool big_decode = max_len == 1 && M <= g_chunk_max_m && g_force_tile == 0;
-    const bool defer_ok = g_defer_norm && !m->f32 && (M <= 64 || (M <= DEFER_MAX_M && big_decode && g_defer_norm == 1)) && !c.use_moe && m->tp == 1 && !m->tp_force && !m->keep_hidden &&
+    // (tensor parallel: the all-reduce launch carries the norm — one-shot payloads only, i.e. M <= 64 — when the P2P group is attached)
+    const bool tp_on = m->tp > 1 || m->tp_force;
+    const bool tp_defer = tp_on && m->p2p_ready && M <= g_p2p_oneshot_rows && M <= 64;
+    const bool defer_ok = g_defer_norm && !m->f32 && (M <= 64 || (M <= DEFER_MAX_M && big_decode && g_defer_norm == 1 && !tp_on)) && !c.use_moe && (!tp_on || tp_defer) && !m->keep_hidden &&
                           c.block_style == NVL_BLOCK_SEQUENTIAL && c.norm_type == NVL_NORM_RMS &&
                           c.activation_type == NVL_ACT_SWIGLU && H % 256 == 0 && m->rs_part && m->n_mamba == 0;
     // MoE layers (decode form): only the O projection carries a norm (the FFN norm); the expert-down projection leaves

@@ -121,6 +121,10 @@ class HipTransformerModel:
         blob = b"".join(handles)
         L.check(self.lib.nvl_tp_p2p_attach(self.h, C.c_char_p(blob), 64), self.h)
 
+    def tp_p2p_rearm(self):
+        """nvl_tp_p2p_rearm: after a timed-out all-reduce, on every rank, while no rank is inside a forward call."""
+        L.check(self.lib.nvl_tp_p2p_rearm(self.h), self.h)
+
     @staticmethod
     def attach_local_group(models):
         arr = (C.c_void_p * len(models))(*[m.h.value for m in models])
