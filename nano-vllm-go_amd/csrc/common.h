@@ -69,6 +69,19 @@ __device__ __forceinline__ void kv_locate(const int32_t* __restrict__ blk_table,
     row = pos - bi * bs;
 }
 
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    // tensor.go:181-190: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))), the tanh in float64 there.
+    // tanh(u) = 1 - 2 / (exp(2u) + 1) on the hardware exp2 / rcp (both ~1 ulp): ABSOLUTE error ~1e-7, and only the absolute
+    // error of tanh enters 1 + tanh; exp -> inf gives exactly 1, exp -> 0 exactly -1.  (libm's tanhf is ~40 instructions per
+    // element; in the prefill epilogue of a K = 768 projection — GPT-2's FFN-up: 64 K elements per 256 x 256 tile — it cost
+    // a third of the launch: 117 us against 81 us for the same-FLOP FFN-down, profiles/r02_gpt2_phase_breakdown.txt.)
+    const float x3 = x * x * x;
+    const float inner = 0.7978845608028654f * (x + 0.044715f * x3);
+    const float e = __builtin_amdgcn_exp2f(inner * 2.8853900817779268f);      // exp(2 inner)
+    const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    return 0.5f * x * (1.0f + th);
+}
+
 // ---- wave reductions (64 lanes) ----------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

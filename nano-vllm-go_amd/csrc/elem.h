@@ -390,9 +390,7 @@ __global__ void swiglu_kernel(const float* __restrict__ h, ActT* __restrict__ y,
 __global__ void gelu_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float v = x[i];
-    const float inner = 0.7978845608028654f * (v + 0.044715f * (v * v * v));
-    y[i] = 0.5f * v * (1.0f + tanhf(inner));
+    y[i] = gelu_tanh_f(x[i]);        // (the same function as the GEMM epilogue: what the op test checks is what the model runs)
 }
 __global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -120,13 +120,6 @@ __device__ __forceinline__ bool moe_expert_live(const GemmArgs& p, int e) {
 }
 
 __device__ __forceinline__ float silu_f(float g) { return g / (1.0f + __expf(-g)); }
-__device__ __forceinline__ float gelu_tanh_f(float x) {
-    // tensor.go:181-190
-    float x3 = x * x * x;
-    float inner = 0.7978845608028654f * (x + 0.044715f * x3);
-    return 0.5f * x * (1.0f + tanhf(inner));
-}
-
 __device__ __forceinline__ float deferred_rstd(const GemmArgs& p, int m);
 
 // ------------------------------------------------------------------------------------------

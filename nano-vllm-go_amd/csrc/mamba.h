@@ -136,6 +136,190 @@ __global__ __launch_bounds__(256) void mamba_scan_kernel(MambaArgs p) {
     for (int i = 0; i < PER; i++) st[i] = s[i];
 }
 
+// ------------------------------------------------------------------------------------------
+// Chunked ("SSD") form of the same recurrence for prefill-sized calls in the bf16 mode: one workgroup of four waves per
+// (sequence, head) walks its tokens in chunks of Q = 64 and does each chunk with MFMA products instead of 64 dependent
+// steps (mamba2.go:256-351 is the sequential statement; this is its algebra).  With a_j = A dt_j, s_t = sum_{j<=t} a_j
+// (inclusive, inside the chunk) and S_in the state entering the chunk:
+//     state_t = exp(s_t) S_in + sum_{j<=t} exp(s_t - s_j) dt_j  u_j (x) B_j
+//     y_t     = exp(s_t) (C_t . S_in) + sum_{j<=t} [exp(s_t - s_j) dt_j (C_t . B_j)] u_j + D u_t
+//     S_out   = exp(s_Q) S_in + sum_j [exp(s_Q - s_j) dt_j u_j] (x) B_j
+// i.e. four products per chunk, all v_mfma_f32_16x16x32_bf16 with fp32 accumulation:
+//     G = C B^T (Q x Q, k = state);  Y_intra = (G o L) U (k = token);  Y_inter = C S_in^T (k = state);  S += (U o w)^T B (k = token)
+// Every decay factor is exp of a NON-POSITIVE fp32 number (s decreases), the state lives in fp32 accumulators across the
+// chunks and is rounded to bf16 only as the Y_inter operand; u, B, C and the masked decay matrix G o L are rounded to bf16 as
+// MFMA operands — the same kind of rounding point the projections around this kernel already have; the
+// fp32 parity mode keeps mamba_scan_kernel.  Operands sit in LDS K-contiguous ([row][k], rows padded by 16 bytes: the
+// fragment reads are conflict-free), B and U additionally transposed.  A ragged last chunk runs with dt = 0 for the missing
+// tokens: they neither decay nor feed the state, and their rows are not stored.
+// ------------------------------------------------------------------------------------------
+template <int HD, int SS>
+constexpr int mamba_ssd_lds_bytes() {
+    return 2 * ((64 * (SS + 8)) * 2 + SS * (64 + 8) + 2 * HD * (64 + 8) + 64 * (64 + 8) + HD * (SS + 8)) + 64 * 4 * 3;
+}
+template <int HD, int SS>
+__global__ __launch_bounds__(256) void mamba_ssd_kernel(MambaArgs p) {
+    constexpr int Q = 64, DT = HD / 16, NT = SS / 16, NP = 4 / DT, NTW = NT / NP;     // d tiles, state tiles, state parts, state tiles per wave
+    constexpr int LC = SS + 8, LQ = Q + 8;                                             // padded row lengths (elements)
+    static_assert(HD == 32 || HD == 64, "head_dim 32 / 64");
+    static_assert(NT % NP == 0, "state tiles must divide over the waves");
+    extern __shared__ __attribute__((aligned(16))) char smem_m[];
+    bf16_t* Cs = (bf16_t*)smem_m;                 // [Q][LC]    C_t[n]
+    bf16_t* Bs = Cs + Q * LC;                     // [Q][LC]    B_j[n]
+    bf16_t* Bt = Bs + Q * LC;                     // [SS][LQ]   B^T
+    bf16_t* Ut = Bt + SS * LQ;                    // [HD][LQ]   U^T
+    bf16_t* Uw = Ut + HD * LQ;                    // [HD][LQ]   (w_j u_j)^T
+    bf16_t* Ms = Uw + HD * LQ;                    // [Q][LQ]    G o L
+    bf16_t* Sb = Ms + Q * LQ;                     // [HD][LC]   bf16 copy of the state entering the chunk
+    float* s_cum = (float*)(Sb + HD * LC);        // [Q] inclusive prefix sums of a_j
+    float* s_dt = s_cum + Q;                      // [Q] dt_j
+    float* s_w = s_dt + Q;                        // [Q] exp(s_Q - s_j) dt_j
+    const int h = blockIdx.x, seq = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int t0 = p.seq_tok_start[seq], n = p.seq_len[seq];
+    const float A = p.a_log ? -__expf(p.a_log[h]) : 0.f;
+    const float Dh = p.Dskip ? p.Dskip[h] : 0.f;
+    int g = h * p.ng / p.nh;
+    if (g >= p.ng) g = p.ng - 1;
+    // ---- the state: wave w owns d tile w % DT and state tiles [(w / DT) * NTW, +NTW) in fp32 accumulators ----
+    const int sd = wave % DT, sn0 = (wave / DT) * NTW;
+    float* st = p.state + (int64_t)p.seq_slot[seq] * p.state_slot_stride + (int64_t)h * HD * SS;
+    f32x4 sacc[NTW];
+    const bool fresh = p.seq_pos[seq] == 0;
+#pragma unroll
+    for (int j = 0; j < NTW; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            sacc[j][r] = fresh ? 0.f : st[(int64_t)(16 * sd + 4 * fg + r) * SS + 16 * (sn0 + j) + fr];
+
+    for (int c0 = 0; c0 < n; c0 += Q) {
+        const int nv = min(Q, n - c0);                          // valid tokens of this chunk
+        __syncthreads();                                        // the previous chunk's LDS readers are done
+        // ---- decay bookkeeping: wave 0 scans a_j = A dt_j ----
+        if (wave == 0) {
+            const float dt = lane < nv ? p.delta[(int64_t)(t0 + c0 + lane) * p.nh + h] : 0.f;
+            float s = A * dt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const float v = __shfl_up(s, o, 64); if (lane >= o) s += v; }
+            s_cum[lane] = s; s_dt[lane] = dt;
+            const float sq = __shfl(s, 63, 64);
+            s_w[lane] = __expf(sq - s) * dt;
+        }
+        // ---- the state entering the chunk, as the bf16 operand of Y_inter ----
+#pragma unroll
+        for (int j = 0; j < NTW; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) Sb[(16 * sd + 4 * fg + r) * LC + 16 * (sn0 + j) + fr] = (bf16_t)sacc[j][r];
+        __syncthreads();
+        // ---- stage u, B, C of the chunk (fp32 rows of xbc -> bf16, K-contiguous; B and u also transposed) ----
+        for (int i = tid; i < Q * (SS / 4); i += 256) {
+            const int t = i / (SS / 4), q4 = (i - t * (SS / 4)) * 4;
+            f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f}, c = b;
+            if (t < nv) {
+                const float* xr = p.xbc + (int64_t)(t0 + c0 + t) * p.conv_dim + p.EH + g * SS + q4;
+                b = *(const f32x4*)xr; c = *(const f32x4*)(xr + p.ng * SS);
+            }
+            bf16x4 bb, cc;
+#pragma unroll
+            for (int r = 0; r < 4; r++) { bb[r] = (bf16_t)b[r]; cc[r] = (bf16_t)c[r]; Bt[(q4 + r) * LQ + t] = (bf16_t)b[r]; }
+            *(bf16x4*)(Bs + t * LC + q4) = bb;
+            *(bf16x4*)(Cs + t * LC + q4) = cc;
+        }
+        for (int i = tid; i < Q * (HD / 4); i += 256) {
+            const int t = i / (HD / 4), d4 = (i - t * (HD / 4)) * 4;
+            f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < nv) u = *(const f32x4*)(p.xbc + (int64_t)(t0 + c0 + t) * p.conv_dim + h * HD + d4);
+            const float w = s_w[t];
+#pragma unroll
+            for (int r = 0; r < 4; r++) { Ut[(d4 + r) * LQ + t] = (bf16_t)u[r]; Uw[(d4 + r) * LQ + t] = (bf16_t)(u[r] * w); }
+        }
+        __syncthreads();
+        // ---- G = C B^T for this wave's 16 tokens (row tile `wave`), causal column tiles only; M = G o L -> LDS ----
+        {
+            const int tt = wave;
+            float srow[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) srow[r] = s_cum[16 * tt + 4 * fg + r];
+            for (int jt = 0; jt < 4; jt++) {
+                f32x4 gacc = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (jt <= tt) {
+#pragma unroll
+                    for (int ks = 0; ks < SS / 32; ks++) {
+                        const bf16x8 af = *(const bf16x8*)(Cs + (16 * tt + fr) * LC + ks * 32 + fg * 8);      // A: rows t, k = state
+                        const bf16x8 bf = *(const bf16x8*)(Bs + (16 * jt + fr) * LC + ks * 32 + fg * 8);      // B: cols j, k = state
+                        gacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, gacc, 0, 0, 0);
+                    }
+                }
+                const int j = 16 * jt + fr;                       // this lane's column (token j), rows t = 16 tt + 4 fg + r
+                const float sj = s_cum[j], dj = s_dt[j];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int t = 16 * tt + 4 * fg + r;
+                    const float v = (j <= t) ? gacc[r] * (__expf(srow[r] - sj) * dj) : 0.f;
+                    Ms[t * LQ + j] = (bf16_t)v;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- y rows of this wave: Y_intra = M U (k = token) and Y_inter = C S_in^T (k = state) ----
+        {
+            const int tt = wave;
+            f32x4 yi[DT], ye[DT];
+#pragma unroll
+            for (int d = 0; d < DT; d++) { yi[d] = f32x4{0.f, 0.f, 0.f, 0.f}; ye[d] = yi[d]; }
+#pragma unroll
+            for (int ks = 0; ks < Q / 32; ks++) {
+                if (ks * 32 > 16 * tt + 15) continue;             // tokens beyond this tile's last row: M is zero there
+                const bf16x8 af = *(const bf16x8*)(Ms + (16 * tt + fr) * LQ + ks * 32 + fg * 8);
+#pragma unroll
+                for (int d = 0; d < DT; d++) {
+                    const bf16x8 bf = *(const bf16x8*)(Ut + (16 * d + fr) * LQ + ks * 32 + fg * 8);
+                    yi[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, yi[d], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < SS / 32; ks++) {
+                const bf16x8 af = *(const bf16x8*)(Cs + (16 * tt + fr) * LC + ks * 32 + fg * 8);
+#pragma unroll
+                for (int d = 0; d < DT; d++) {
+                    const bf16x8 bf = *(const bf16x8*)(Sb + (16 * d + fr) * LC + ks * 32 + fg * 8);
+                    ye[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, ye[d], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int t = 16 * tt + 4 * fg + r;
+                if (t >= nv) continue;
+                const float es = __expf(s_cum[t]);
+                const float* ur = p.xbc + (int64_t)(t0 + c0 + t) * p.conv_dim + h * HD;
+                float* yr = p.y + (int64_t)(t0 + c0 + t) * p.EH + h * HD;
+#pragma unroll
+                for (int d = 0; d < DT; d++) yr[16 * d + fr] = yi[d][r] + es * ye[d][r] + Dh * ur[16 * d + fr];
+            }
+        }
+        // ---- S_out = exp(s_Q) S_in + (U o w)^T B  (k = token) ----
+        {
+            const float eq = __expf(s_cum[Q - 1]);
+#pragma unroll
+            for (int j = 0; j < NTW; j++) sacc[j] *= eq;
+#pragma unroll
+            for (int ks = 0; ks < Q / 32; ks++) {
+                const bf16x8 af = *(const bf16x8*)(Uw + (16 * sd + fr) * LQ + ks * 32 + fg * 8);              // A: rows d, k = token
+#pragma unroll
+                for (int j = 0; j < NTW; j++) {
+                    const bf16x8 bf = *(const bf16x8*)(Bt + (16 * (sn0 + j) + fr) * LQ + ks * 32 + fg * 8);   // B: cols n, k = token
+                    sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, sacc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) st[(int64_t)(16 * sd + 4 * fg + r) * SS + 16 * (sn0 + j) + fr] = sacc[j][r];
+}
+
 // grid (tokens), 256 threads: y *= SiLU(gate); rms over EH; * norm weight; written as the out_proj GEMM's operand
 template <typename ActT>
 __global__ __launch_bounds__(256) void mamba_gate_norm_kernel(MambaArgs p, ActT* __restrict__ out) {

@@ -1299,6 +1299,7 @@ static int g_moe_deep = 1;     // nvl_set_tuning key 19: four-stage grouped GEMM
 static int g_moe_bm = 0;       // nvl_set_tuning key 17: prefill MoE grouped GEMMs: 0 = 256-row tiles on the ping-pong kernel, 128 / 256 = the lock-step tile kernels
 static int g_moe_gather = 1;   // nvl_set_tuning key 16: prefill MoE gathers the token rows into expert order before the grouped GEMM (0 = per-lane gather inside it)
 static int g_moe_small = 1;    // nvl_set_tuning key 8: fused MoE planning launch + combine folded into the next norm (0 = off)
+static int g_mamba_ssd = 1;    // nvl_set_tuning key 30: chunked (SSD) Mamba2 scan on MFMA for prefill-sized bf16 calls (0 = the sequential scan)
 static int g_decode_seam = 1;  // nvl_set_tuning key 7: decode_seam_kernel in nvl_decode_greedy (0 = separate kernels)
 static int g_defer_norm = 1;   // nvl_set_tuning key 3: deferred RMSNorm between O-proj and FFN-up in decode (0 = off)
 static int g_sk_slices = 0;    // tuning override (nvl_set_tuning key 1): 0 automatic, 1 = never split
@@ -1640,6 +1641,20 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
                           (double)M * (m->mConv + m->m_nh + m->mEH) * 4.0 + 2.0 * n_seqs * (double)m->ssm_layer_stride * 4.0);
                 const int per = m->m_ss / (256 / m->m_hd);
                 dim3 grid(m->m_nh, n_seqs);
+                // prefill-sized calls, bf16 mode: the chunked (SSD) form on MFMA — 64 tokens per step instead of one
+                const bool ssd = g_mamba_ssd && !m->f32 && max_len >= 16 && (m->m_hd == 32 || m->m_hd == 64) &&
+                                 (m->m_ss == 32 || m->m_ss == 64 || m->m_ss == 128) && m->mConv % 4 == 0 && m->mEH % 4 == 0;
+#define NVL_SSD(HDv, SSv)                                                                                              \
+                do {                                                                                                   \
+                    constexpr int lds_ = mamba_ssd_lds_bytes<HDv, SSv>();                                              \
+                    NVL_LDS_ATTR((mamba_ssd_kernel<HDv, SSv>), lds_);                                                  \
+                    hipLaunchKernelGGL((mamba_ssd_kernel<HDv, SSv>), grid, dim3(256), lds_, m->stream, a);             \
+                } while (0)
+                if (ssd) {
+                    if (m->m_hd == 64) { if (m->m_ss == 128) NVL_SSD(64, 128); else if (m->m_ss == 64) NVL_SSD(64, 64); else NVL_SSD(64, 32); }
+                    else { if (m->m_ss == 128) NVL_SSD(32, 128); else if (m->m_ss == 64) NVL_SSD(32, 64); else NVL_SSD(32, 32); }
+                } else
+#undef NVL_SSD
                 if (per <= 4) hipLaunchKernelGGL(mamba_scan_kernel<4>, grid, dim3(256), 0, m->stream, a);
                 else if (per <= 8) hipLaunchKernelGGL(mamba_scan_kernel<8>, grid, dim3(256), 0, m->stream, a);
                 else if (per <= 16) hipLaunchKernelGGL(mamba_scan_kernel<16>, grid, dim3(256), 0, m->stream, a);

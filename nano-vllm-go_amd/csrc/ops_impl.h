@@ -422,5 +422,6 @@ extern "C" int nvl_set_tuning(int key, int value) {
     if (key == 2) { const int old = g_force_ntw; g_force_ntw = value; return old; }
     if (key == 27) { const int old = g_half_tiles; g_half_tiles = value; return old; }
     if (key == 29) { const int old = g_p2p_spin_ms; g_p2p_spin_ms = value; return old; }
+    if (key == 30) { const int old = g_mamba_ssd; g_mamba_ssd = value; return old; }
     return -1;
 }

@@ -164,6 +164,50 @@ def test_runner_chunked_prefill_of_a_long_history_matches_one_forward(gpu, oracl
         hm.close()
 
 
+@pytest.mark.parametrize("variant", range(len(VARIANTS)))
+def test_chunked_ssd_scan_matches_oracle_and_the_sequential_scan(gpu, oracle, variant):
+    """csrc/mamba.h mamba_ssd_kernel (prefill-sized bf16 calls: 64 tokens per MFMA step) against the oracle's sequential
+    recurrence (mamba2.go:256-351) and against the sequential device kernel (tuning key 30 = 0): a ragged batch of three
+    sequences (lengths straddling the 64-token chunk), then a continuation of each on its carried state (seq_pos > 0)."""
+    cfg = gpu.synth.tiny_config("granite_hybrid", **dict(VARIANTS[variant], max_seq_len=512))
+    w = gpu.synth.make_weights(cfg, seed=17, scale=0.05)
+    r = np.random.default_rng(50 + variant)
+    lens = (200, 64, 129)
+    prompts = [r.integers(0, cfg["vocab_size"], n).tolist() for n in lens]
+    more = [r.integers(0, cfg["vocab_size"], n).tolist() for n in (70, 17, 33)]
+    want, want2, states = [], [], []
+    for p_, q_ in zip(prompts, more):
+        om = oracle.OracleModel(cfg, w)
+        kv = om.new_cache()
+        want.append(om.forward_with_cache(p_, kv, 0)[-1])
+        want2.append(om.forward_with_cache(q_, kv, len(p_))[-1])
+        states.append([om.mamba_state(li) for li, k in enumerate(cfg["hybrid_layers"]) if k == "mamba"])
+    got = {}
+    for ssd in (1, 0):
+        old = gpu.lib().nvl_set_tuning(30, ssd)
+        try:
+            hm = gpu.HipTransformerModel(cfg, w, precision="bf16", max_seqs=4, max_batch_tokens=512)
+            ids = [0, 1, 2]
+            for i in ids:
+                hm.seq_reset(i)
+            a, _ = hm.forward_batch(ids, prompts, [0, 0, 0])
+            b, _ = hm.forward_batch(ids, more, list(lens))
+            st = [[hm.get_mamba_state(i, li) for li, k in enumerate(cfg["hybrid_layers"]) if k == "mamba"] for i in ids]
+            got[ssd] = (a, b, st)
+            hm.close()
+        finally:
+            gpu.lib().nvl_set_tuning(30, old)
+    for ssd in (1, 0):
+        a, b, st = got[ssd]
+        for i in range(3):
+            assert rel_err(a[i], want[i]) <= TOL["bf16"], (ssd, "prefill", i)
+            assert rel_err(b[i], want2[i]) <= TOL["bf16"], (ssd, "continuation", i)
+            for x, y in zip(st[i], states[i]):
+                assert rel_err(x, y) <= TOL["bf16"], (ssd, "state", i)
+    # the two device forms agree much more closely with each other than either needs to with the oracle
+    assert rel_err(got[1][0], got[0][0]) <= 6e-3 and rel_err(got[1][1], got[0][1]) <= 6e-3
+
+
 def test_hybrid_is_refused_where_it_cannot_work(gpu):
     cfg = gpu.synth.tiny_config("granite_hybrid")
     with pytest.raises(gpu.NvlError):                       # per-sequence state lives in KV slots: no paged mode
