@@ -46,6 +46,9 @@ struct MambaArgs {
     float* tail;                   // this layer's tails: slot s at tail + s * tail_slot_stride, [K-1][conv_dim]
     int64_t tail_slot_stride;
     int chain;
+    // chunk-parallel SSD scan (mamba_ssd_kernel MODE 1 / 2): per (sequence, chunk, head) state scratch and chunk decay
+    float* ssd_z;                  // [sequences][max_chunks][nh][hd][ss]
+    float* ssd_decay;              // [sequences][max_chunks][nh]
 };
 
 __device__ __forceinline__ float silu_ref(float x) { return x / (1.0f + __expf(-x)); }
@@ -157,7 +160,14 @@ template <int HD, int SS>
 constexpr int mamba_ssd_lds_bytes() {
     return 2 * ((64 * (SS + 8)) * 2 + SS * (64 + 8) + 2 * HD * (64 + 8) + 64 * (64 + 8) + HD * (SS + 8)) + 64 * 4 * 3;
 }
-template <int HD, int SS>
+// MODE 0: one workgroup per (sequence, head) walks the chunks in order (the state stays in its accumulators).
+// With few (sequence, head) pairs and long prompts that leaves most of the chip idle, so the chunks can run in parallel:
+// MODE 1: grid.z = chunks; each workgroup computes only ITS chunk's contribution to the state from a zero state,
+//         Z_c = (U o w)^T B, and the chunk's total decay exp(s_Q) -> scratch;
+// mamba_ssd_prefix_kernel: per (sequence, head) the short recurrence S_{c+1} = decay_c S_c + Z_c over the chunks (elementwise),
+//         leaving S_c (the state ENTERING chunk c) in the scratch slot of chunk c and the final state in the slot state;
+// MODE 2: grid.z = chunks; each workgroup loads the state entering its chunk and computes the chunk's outputs.
+template <int HD, int SS, int MODE = 0>
 __global__ __launch_bounds__(256) void mamba_ssd_kernel(MambaArgs p) {
     constexpr int Q = 64, DT = HD / 16, NT = SS / 16, NP = 4 / DT, NTW = NT / NP;     // d tiles, state tiles, state parts, state tiles per wave
     constexpr int LC = SS + 8, LQ = Q + 8;                                             // padded row lengths (elements)
@@ -178,6 +188,7 @@ __global__ __launch_bounds__(256) void mamba_ssd_kernel(MambaArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int t0 = p.seq_tok_start[seq], n = p.seq_len[seq];
+    if (MODE != 0 && (int)blockIdx.z * Q >= n) return;          // (uniform: before any barrier)
     const float A = p.a_log ? -__expf(p.a_log[h]) : 0.f;
     const float Dh = p.Dskip ? p.Dskip[h] : 0.f;
     int g = h * p.ng / p.nh;
@@ -185,15 +196,19 @@ __global__ __launch_bounds__(256) void mamba_ssd_kernel(MambaArgs p) {
     // ---- the state: wave w owns d tile w % DT and state tiles [(w / DT) * NTW, +NTW) in fp32 accumulators ----
     const int sd = wave % DT, sn0 = (wave / DT) * NTW;
     float* st = p.state + (int64_t)p.seq_slot[seq] * p.state_slot_stride + (int64_t)h * HD * SS;
+    // chunk-parallel modes: this (sequence, head, chunk)'s scratch slot
+    float* zs = MODE != 0 ? p.ssd_z + (((int64_t)seq * gridDim.z + blockIdx.z) * p.nh + h) * (HD * SS) : nullptr;
     f32x4 sacc[NTW];
     const bool fresh = p.seq_pos[seq] == 0;
 #pragma unroll
     for (int j = 0; j < NTW; j++)
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-            sacc[j][r] = fresh ? 0.f : st[(int64_t)(16 * sd + 4 * fg + r) * SS + 16 * (sn0 + j) + fr];
+        for (int r = 0; r < 4; r++) {
+            const int64_t o = (int64_t)(16 * sd + 4 * fg + r) * SS + 16 * (sn0 + j) + fr;
+            sacc[j][r] = MODE == 1 ? 0.f : (MODE == 2 ? zs[o] : (fresh ? 0.f : st[o]));
+        }
 
-    for (int c0 = 0; c0 < n; c0 += Q) {
+    for (int c0 = MODE == 0 ? 0 : (int)blockIdx.z * Q; c0 < (MODE == 0 ? n : (int)blockIdx.z * Q + 1); c0 += Q) {
         const int nv = min(Q, n - c0);                          // valid tokens of this chunk
         __syncthreads();                                        // the previous chunk's LDS readers are done
         // ---- decay bookkeeping: wave 0 scans a_j = A dt_j ----
@@ -207,10 +222,12 @@ __global__ __launch_bounds__(256) void mamba_ssd_kernel(MambaArgs p) {
             s_w[lane] = __expf(sq - s) * dt;
         }
         // ---- the state entering the chunk, as the bf16 operand of Y_inter ----
+        if (MODE != 1) {
 #pragma unroll
-        for (int j = 0; j < NTW; j++)
+            for (int j = 0; j < NTW; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) Sb[(16 * sd + 4 * fg + r) * LC + 16 * (sn0 + j) + fr] = (bf16_t)sacc[j][r];
+                for (int r = 0; r < 4; r++) Sb[(16 * sd + 4 * fg + r) * LC + 16 * (sn0 + j) + fr] = (bf16_t)sacc[j][r];
+        }
         __syncthreads();
         // ---- stage u, B, C of the chunk (fp32 rows of xbc -> bf16, K-contiguous; B and u also transposed) ----
         for (int i = tid; i < Q * (SS / 4); i += 256) {
@@ -218,13 +235,13 @@ __global__ __launch_bounds__(256) void mamba_ssd_kernel(MambaArgs p) {
             f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f}, c = b;
             if (t < nv) {
                 const float* xr = p.xbc + (int64_t)(t0 + c0 + t) * p.conv_dim + p.EH + g * SS + q4;
-                b = *(const f32x4*)xr; c = *(const f32x4*)(xr + p.ng * SS);
+                b = *(const f32x4*)xr;
+                if (MODE != 1) c = *(const f32x4*)(xr + p.ng * SS);
             }
             bf16x4 bb, cc;
 #pragma unroll
-            for (int r = 0; r < 4; r++) { bb[r] = (bf16_t)b[r]; cc[r] = (bf16_t)c[r]; Bt[(q4 + r) * LQ + t] = (bf16_t)b[r]; }
-            *(bf16x4*)(Bs + t * LC + q4) = bb;
-            *(bf16x4*)(Cs + t * LC + q4) = cc;
+            for (int r = 0; r < 4; r++) { bb[r] = (bf16_t)b[r]; cc[r] = (bf16_t)c[r]; if (MODE != 2) Bt[(q4 + r) * LQ + t] = (bf16_t)b[r]; }
+            if (MODE != 1) { *(bf16x4*)(Bs + t * LC + q4) = bb; *(bf16x4*)(Cs + t * LC + q4) = cc; }
         }
         for (int i = tid; i < Q * (HD / 4); i += 256) {
             const int t = i / (HD / 4), d4 = (i - t * (HD / 4)) * 4;
@@ -232,74 +249,79 @@ __global__ __launch_bounds__(256) void mamba_ssd_kernel(MambaArgs p) {
             if (t < nv) u = *(const f32x4*)(p.xbc + (int64_t)(t0 + c0 + t) * p.conv_dim + h * HD + d4);
             const float w = s_w[t];
 #pragma unroll
-            for (int r = 0; r < 4; r++) { Ut[(d4 + r) * LQ + t] = (bf16_t)u[r]; Uw[(d4 + r) * LQ + t] = (bf16_t)(u[r] * w); }
+            for (int r = 0; r < 4; r++) {
+                if (MODE != 1) Ut[(d4 + r) * LQ + t] = (bf16_t)u[r];
+                if (MODE != 2) Uw[(d4 + r) * LQ + t] = (bf16_t)(u[r] * w);
+            }
         }
         __syncthreads();
-        // ---- G = C B^T for this wave's 16 tokens (row tile `wave`), causal column tiles only; M = G o L -> LDS ----
-        {
-            const int tt = wave;
-            float srow[4];
+        if (MODE != 1) {
+            // ---- G = C B^T for this wave's 16 tokens (row tile `wave`), causal column tiles only; M = G o L -> LDS ----
+            {
+                const int tt = wave;
+                float srow[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) srow[r] = s_cum[16 * tt + 4 * fg + r];
-            for (int jt = 0; jt < 4; jt++) {
-                f32x4 gacc = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (jt <= tt) {
+                for (int r = 0; r < 4; r++) srow[r] = s_cum[16 * tt + 4 * fg + r];
+                for (int jt = 0; jt < 4; jt++) {
+                    f32x4 gacc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (jt <= tt) {
 #pragma unroll
-                    for (int ks = 0; ks < SS / 32; ks++) {
-                        const bf16x8 af = *(const bf16x8*)(Cs + (16 * tt + fr) * LC + ks * 32 + fg * 8);      // A: rows t, k = state
-                        const bf16x8 bf = *(const bf16x8*)(Bs + (16 * jt + fr) * LC + ks * 32 + fg * 8);      // B: cols j, k = state
-                        gacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, gacc, 0, 0, 0);
+                        for (int ks = 0; ks < SS / 32; ks++) {
+                            const bf16x8 af = *(const bf16x8*)(Cs + (16 * tt + fr) * LC + ks * 32 + fg * 8);      // A: rows t, k = state
+                            const bf16x8 bf = *(const bf16x8*)(Bs + (16 * jt + fr) * LC + ks * 32 + fg * 8);      // B: cols j, k = state
+                            gacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, gacc, 0, 0, 0);
+                        }
+                    }
+                    const int j = 16 * jt + fr;                       // this lane's column (token j), rows t = 16 tt + 4 fg + r
+                    const float sj = s_cum[j], dj = s_dt[j];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int t = 16 * tt + 4 * fg + r;
+                        const float v = (j <= t) ? gacc[r] * (__expf(srow[r] - sj) * dj) : 0.f;
+                        Ms[t * LQ + j] = (bf16_t)v;
                     }
                 }
-                const int j = 16 * jt + fr;                       // this lane's column (token j), rows t = 16 tt + 4 fg + r
-                const float sj = s_cum[j], dj = s_dt[j];
+            }
+            __syncthreads();
+            // ---- y rows of this wave: Y_intra = M U (k = token) and Y_inter = C S_in^T (k = state) ----
+            {
+                const int tt = wave;
+                f32x4 yi[DT], ye[DT];
+#pragma unroll
+                for (int d = 0; d < DT; d++) { yi[d] = f32x4{0.f, 0.f, 0.f, 0.f}; ye[d] = yi[d]; }
+#pragma unroll
+                for (int ks = 0; ks < Q / 32; ks++) {
+                    if (ks * 32 > 16 * tt + 15) continue;             // tokens beyond this tile's last row: M is zero there
+                    const bf16x8 af = *(const bf16x8*)(Ms + (16 * tt + fr) * LQ + ks * 32 + fg * 8);
+#pragma unroll
+                    for (int d = 0; d < DT; d++) {
+                        const bf16x8 bf = *(const bf16x8*)(Ut + (16 * d + fr) * LQ + ks * 32 + fg * 8);
+                        yi[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, yi[d], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int ks = 0; ks < SS / 32; ks++) {
+                    const bf16x8 af = *(const bf16x8*)(Cs + (16 * tt + fr) * LC + ks * 32 + fg * 8);
+#pragma unroll
+                    for (int d = 0; d < DT; d++) {
+                        const bf16x8 bf = *(const bf16x8*)(Sb + (16 * d + fr) * LC + ks * 32 + fg * 8);
+                        ye[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, ye[d], 0, 0, 0);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int t = 16 * tt + 4 * fg + r;
-                    const float v = (j <= t) ? gacc[r] * (__expf(srow[r] - sj) * dj) : 0.f;
-                    Ms[t * LQ + j] = (bf16_t)v;
+                    if (t >= nv) continue;
+                    const float es = __expf(s_cum[t]);
+                    const float* ur = p.xbc + (int64_t)(t0 + c0 + t) * p.conv_dim + h * HD;
+                    float* yr = p.y + (int64_t)(t0 + c0 + t) * p.EH + h * HD;
+#pragma unroll
+                    for (int d = 0; d < DT; d++) yr[16 * d + fr] = yi[d][r] + es * ye[d][r] + Dh * ur[16 * d + fr];
                 }
             }
         }
-        __syncthreads();
-        // ---- y rows of this wave: Y_intra = M U (k = token) and Y_inter = C S_in^T (k = state) ----
-        {
-            const int tt = wave;
-            f32x4 yi[DT], ye[DT];
-#pragma unroll
-            for (int d = 0; d < DT; d++) { yi[d] = f32x4{0.f, 0.f, 0.f, 0.f}; ye[d] = yi[d]; }
-#pragma unroll
-            for (int ks = 0; ks < Q / 32; ks++) {
-                if (ks * 32 > 16 * tt + 15) continue;             // tokens beyond this tile's last row: M is zero there
-                const bf16x8 af = *(const bf16x8*)(Ms + (16 * tt + fr) * LQ + ks * 32 + fg * 8);
-#pragma unroll
-                for (int d = 0; d < DT; d++) {
-                    const bf16x8 bf = *(const bf16x8*)(Ut + (16 * d + fr) * LQ + ks * 32 + fg * 8);
-                    yi[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, yi[d], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < SS / 32; ks++) {
-                const bf16x8 af = *(const bf16x8*)(Cs + (16 * tt + fr) * LC + ks * 32 + fg * 8);
-#pragma unroll
-                for (int d = 0; d < DT; d++) {
-                    const bf16x8 bf = *(const bf16x8*)(Sb + (16 * d + fr) * LC + ks * 32 + fg * 8);
-                    ye[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, ye[d], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int t = 16 * tt + 4 * fg + r;
-                if (t >= nv) continue;
-                const float es = __expf(s_cum[t]);
-                const float* ur = p.xbc + (int64_t)(t0 + c0 + t) * p.conv_dim + h * HD;
-                float* yr = p.y + (int64_t)(t0 + c0 + t) * p.EH + h * HD;
-#pragma unroll
-                for (int d = 0; d < DT; d++) yr[16 * d + fr] = yi[d][r] + es * ye[d][r] + Dh * ur[16 * d + fr];
-            }
-        }
-        // ---- S_out = exp(s_Q) S_in + (U o w)^T B  (k = token) ----
-        {
+        if (MODE != 2) {
+            // ---- S_out = exp(s_Q) S_in + (U o w)^T B  (k = token) ----
             const float eq = __expf(s_cum[Q - 1]);
 #pragma unroll
             for (int j = 0; j < NTW; j++) sacc[j] *= eq;
@@ -312,12 +334,44 @@ __global__ __launch_bounds__(256) void mamba_ssd_kernel(MambaArgs p) {
                     sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, sacc[j], 0, 0, 0);
                 }
             }
+            if (MODE == 1 && tid == 0) p.ssd_decay[((int64_t)seq * gridDim.z + blockIdx.z) * p.nh + h] = eq;
         }
     }
+    if (MODE == 2) return;
+    float* dst = MODE == 1 ? zs : st;
 #pragma unroll
     for (int j = 0; j < NTW; j++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) st[(int64_t)(16 * sd + 4 * fg + r) * SS + 16 * (sn0 + j) + fr] = sacc[j][r];
+        for (int r = 0; r < 4; r++) dst[(int64_t)(16 * sd + 4 * fg + r) * SS + 16 * (sn0 + j) + fr] = sacc[j][r];
+}
+
+// the chunk recurrence of the chunk-parallel form: grid (nh, sequences, state_elems / 1024), one f32x4 of the head's hd x ss
+// state per thread; the chunks are walked four at a time so that four slots' loads are in flight per round trip
+__global__ __launch_bounds__(256) void mamba_ssd_prefix_kernel(MambaArgs p, int max_chunks, int state_elems) {
+    const int h = blockIdx.x, seq = blockIdx.y;
+    const int e = (blockIdx.z * 256 + threadIdx.x) * 4;
+    if (e >= state_elems) return;
+    const int nc = (p.seq_len[seq] + 63) / 64;
+    float* st = p.state + (int64_t)p.seq_slot[seq] * p.state_slot_stride + (int64_t)h * state_elems + e;
+    f32x4 run = p.seq_pos[seq] == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)st;
+    const int64_t slot0 = (int64_t)seq * max_chunks * p.nh + h;          // slot of chunk c: slot0 + c * nh
+    for (int c0 = 0; c0 < nc; c0 += 4) {
+        f32x4 z[4];
+        float dc[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int c = min(c0 + i, nc - 1);
+            z[i] = *(const f32x4*)(p.ssd_z + (slot0 + (int64_t)c * p.nh) * state_elems + e);
+            dc[i] = p.ssd_decay[slot0 + (int64_t)c * p.nh];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (c0 + i >= nc) break;
+            *(f32x4*)(p.ssd_z + (slot0 + (int64_t)(c0 + i) * p.nh) * state_elems + e) = run;      // the state entering chunk c
+            run = dc[i] * run + z[i];
+        }
+    }
+    *(f32x4*)st = run;
 }
 
 // grid (tokens), 256 threads: y *= SiLU(gate); rms over EH; * norm weight; written as the out_proj GEMM's operand

@@ -145,6 +145,7 @@ struct nvl_model {
     float *mproj = nullptr, *mxbc = nullptr, *mdelta = nullptr, *my = nullptr; void* myn = nullptr;
     float* conv_tail = nullptr; int64_t conv_tail_layer_stride = 0, conv_tail_slot_stride = 0;   // chunked prefill only (mamba.h MambaArgs::chain)
     int conv_chain = 0;          // set by runner_impl around the chunks of one long history
+    float *ssd_z = nullptr, *ssd_decay = nullptr; int64_t ssd_z_floats = 0, ssd_decay_floats = 0;   // chunk-parallel SSD scan scratch (mamba.h)
     SampleBufs samp;             // nvl_sample scratch
     int32_t* samp_hist = nullptr; int32_t* samp_hist_len = nullptr; int64_t samp_hist_cap = 0;   // nvl_decode_sampled: device-kept histories
     float* samp_u_steps = nullptr; int64_t samp_u_cap = 0;

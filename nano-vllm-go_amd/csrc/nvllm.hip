@@ -336,7 +336,7 @@ extern "C" void nvl_destroy(nvl_model* m) {
     clear_graphs(m);
     if (m->am_host) (void)hipHostFree(m->am_host);
     dfree(m->ring_pos0);
-    dfree(m->conv_tail); dfree(m->stamp_buf);
+    dfree(m->conv_tail); dfree(m->stamp_buf); dfree(m->ssd_z); dfree(m->ssd_decay);
     dfree(m->ssm_state); dfree(m->mproj); dfree(m->mxbc); dfree(m->mdelta); dfree(m->my); dfree(m->myn);
     free_sample_bufs(m->samp);
     dfree(m->samp_hist); dfree(m->samp_hist_len); dfree(m->samp_u_steps);
@@ -1299,7 +1299,8 @@ static int g_moe_deep = 1;     // nvl_set_tuning key 19: four-stage grouped GEMM
 static int g_moe_bm = 0;       // nvl_set_tuning key 17: prefill MoE grouped GEMMs: 0 = 256-row tiles on the ping-pong kernel, 128 / 256 = the lock-step tile kernels
 static int g_moe_gather = 1;   // nvl_set_tuning key 16: prefill MoE gathers the token rows into expert order before the grouped GEMM (0 = per-lane gather inside it)
 static int g_moe_small = 1;    // nvl_set_tuning key 8: fused MoE planning launch + combine folded into the next norm (0 = off)
-static int g_mamba_ssd = 1;    // nvl_set_tuning key 30: chunked (SSD) Mamba2 scan on MFMA for prefill-sized bf16 calls (0 = the sequential scan)
+static int g_mamba_ssd = 1;    // nvl_set_tuning key 30: chunked (SSD) Mamba2 scan on MFMA for prefill-sized bf16 calls (0 = the sequential scan,
+                               // 2 = chunk after chunk only, never the chunk-parallel three-launch form)
 static int g_decode_seam = 1;  // nvl_set_tuning key 7: decode_seam_kernel in nvl_decode_greedy (0 = separate kernels)
 static int g_defer_norm = 1;   // nvl_set_tuning key 3: deferred RMSNorm between O-proj and FFN-up in decode (0 = off)
 static int g_sk_slices = 0;    // tuning override (nvl_set_tuning key 1): 0 automatic, 1 = never split
@@ -1644,11 +1645,40 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
                 // prefill-sized calls, bf16 mode: the chunked (SSD) form on MFMA — 64 tokens per step instead of one
                 const bool ssd = g_mamba_ssd && !m->f32 && max_len >= 16 && (m->m_hd == 32 || m->m_hd == 64) &&
                                  (m->m_ss == 32 || m->m_ss == 64 || m->m_ss == 128) && m->mConv % 4 == 0 && m->mEH % 4 == 0;
+                // (sequence, head) pairs for fewer than half the CUs and several chunks: the chunks of a sequence in parallel (state
+                // contributions, a short recurrence over the chunks, outputs: three launches; 1 x 2048: 318 -> 90 us per layer) —
+                // with a workgroup per CU already (8 x 512) the extra state traffic loses (86 -> 174 us); scratch capped at 256 MB
+                const int max_chunks = cdiv(max_len, 64);
+                const int64_t z_floats = (int64_t)n_seqs * max_chunks * m->m_nh * m->m_hd * m->m_ss;
+                const bool par = ssd && g_mamba_ssd >= 1 && g_mamba_ssd != 2 && max_chunks >= 4 && m->m_nh * n_seqs < 128 && z_floats * 4 <= (256ll << 20);
+                if (par && z_floats > m->ssd_z_floats) {
+                    NVL_HIP(hipStreamSynchronize(m->stream));
+                    dfree(m->ssd_z); dfree(m->ssd_decay);
+                    m->ssd_z = dmalloc<float>(z_floats); m->ssd_z_floats = z_floats;
+                    m->ssd_decay = dmalloc<float>((int64_t)n_seqs * max_chunks * m->m_nh + 1024);
+                    m->ssd_decay_floats = (int64_t)n_seqs * max_chunks * m->m_nh + 1024;
+                }
+                if (par && (int64_t)n_seqs * max_chunks * m->m_nh > m->ssd_decay_floats) {
+                    NVL_HIP(hipStreamSynchronize(m->stream));
+                    dfree(m->ssd_decay);
+                    m->ssd_decay_floats = (int64_t)n_seqs * max_chunks * m->m_nh + 1024;
+                    m->ssd_decay = dmalloc<float>(m->ssd_decay_floats);
+                }
+                a.ssd_z = m->ssd_z; a.ssd_decay = m->ssd_decay;
 #define NVL_SSD(HDv, SSv)                                                                                              \
                 do {                                                                                                   \
                     constexpr int lds_ = mamba_ssd_lds_bytes<HDv, SSv>();                                              \
-                    NVL_LDS_ATTR((mamba_ssd_kernel<HDv, SSv>), lds_);                                                  \
-                    hipLaunchKernelGGL((mamba_ssd_kernel<HDv, SSv>), grid, dim3(256), lds_, m->stream, a);             \
+                    if (par) {                                                                                         \
+                        dim3 g3(m->m_nh, n_seqs, max_chunks);                                                          \
+                        NVL_LDS_ATTR((mamba_ssd_kernel<HDv, SSv, 1>), lds_);                                           \
+                        NVL_LDS_ATTR((mamba_ssd_kernel<HDv, SSv, 2>), lds_);                                           \
+                        hipLaunchKernelGGL((mamba_ssd_kernel<HDv, SSv, 1>), g3, dim3(256), lds_, m->stream, a);        \
+                        hipLaunchKernelGGL(mamba_ssd_prefix_kernel, dim3(m->m_nh, n_seqs, cdiv(HDv * SSv, 1024)), dim3(256), 0, m->stream, a, max_chunks, HDv * SSv); \
+                        hipLaunchKernelGGL((mamba_ssd_kernel<HDv, SSv, 2>), g3, dim3(256), lds_, m->stream, a);        \
+                    } else {                                                                                           \
+                        NVL_LDS_ATTR((mamba_ssd_kernel<HDv, SSv, 0>), lds_);                                           \
+                        hipLaunchKernelGGL((mamba_ssd_kernel<HDv, SSv, 0>), grid, dim3(256), lds_, m->stream, a);      \
+                    }                                                                                                  \
                 } while (0)
                 if (ssd) {
                     if (m->m_hd == 64) { if (m->m_ss == 128) NVL_SSD(64, 128); else if (m->m_ss == 64) NVL_SSD(64, 64); else NVL_SSD(64, 32); }

@@ -20,7 +20,8 @@ hm = pkg.HipTransformerModel(cfg, w, precision="bf16", max_seqs=B, max_batch_tok
 rng = np.random.default_rng(0)
 prompts = [rng.integers(0, cfg["vocab_size"], S).tolist() for _ in range(B)]
 ids = list(range(B))
-for ssd in (1, 0, 1, 0):
+NAMES = {1: "chunked SSD scan, chunks in parallel", 2: "chunked SSD scan, chunk after chunk ", 0: "sequential scan                     "}
+for ssd in (1, 2, 0, 1, 2, 0):
     pkg.lib().nvl_set_tuning(30, ssd)
     best = 1e9
     for rep in range(4):
@@ -29,9 +30,9 @@ for ssd in (1, 0, 1, 0):
         t0 = time.perf_counter()
         hm.forward_batch(ids, prompts, [0] * B, want_logits=False)
         best = min(best, time.perf_counter() - t0)
-    print(f"hybrid prefill B={B} S={S}: {'chunked SSD scan' if ssd else 'sequential scan '}: {B * S / best:10.0f} tok/s ({best * 1e3:.2f} ms)")
+    print(f"hybrid prefill B={B} S={S}: {NAMES[ssd]}: {B * S / best:10.0f} tok/s ({best * 1e3:.2f} ms)")
 hm.set_profile(True)
-for ssd in (1, 0):
+for ssd in (1, 2, 0):
     pkg.lib().nvl_set_tuning(30, ssd)
     hm.reset_stats()
     for i in ids:
@@ -39,5 +40,5 @@ for ssd in (1, 0):
     hm.forward_batch(ids, prompts, [0] * B, want_logits=False)
     ks = {k["site"]: k for k in hm.kernel_stats() if k["phase"] == "prefill"}
     sc = ks.get("mamba_scan")
-    print(f"  {'chunked' if ssd else 'sequential'}: mamba_scan {1e3 * sc['ms'] / sc['launches']:.1f} us per layer; " +
+    print(f"  {NAMES[ssd].strip()}: mamba_scan {1e3 * sc['ms'] / sc['launches']:.1f} us per layer; " +
           ", ".join(f"{n} {1e3 * v['ms'] / v['launches']:.1f}" for n, v in ks.items() if n.startswith("mamba") and n != "mamba_scan"))

@@ -168,7 +168,8 @@ def test_runner_chunked_prefill_of_a_long_history_matches_one_forward(gpu, oracl
 def test_chunked_ssd_scan_matches_oracle_and_the_sequential_scan(gpu, oracle, variant):
     """csrc/mamba.h mamba_ssd_kernel (prefill-sized bf16 calls: 64 tokens per MFMA step) against the oracle's sequential
     recurrence (mamba2.go:256-351) and against the sequential device kernel (tuning key 30 = 0): a ragged batch of three
-    sequences (lengths straddling the 64-token chunk), then a continuation of each on its carried state (seq_pos > 0)."""
+    sequences (lengths straddling the 64-token chunk), then a continuation of each on its carried state (seq_pos > 0).
+    Key 30 = 1 takes the chunk-parallel three-launch form here (four chunks, few heads), 2 the chunk-after-chunk form."""
     cfg = gpu.synth.tiny_config("granite_hybrid", **dict(VARIANTS[variant], max_seq_len=512))
     w = gpu.synth.make_weights(cfg, seed=17, scale=0.05)
     r = np.random.default_rng(50 + variant)
@@ -183,7 +184,7 @@ def test_chunked_ssd_scan_matches_oracle_and_the_sequential_scan(gpu, oracle, va
         want2.append(om.forward_with_cache(q_, kv, len(p_))[-1])
         states.append([om.mamba_state(li) for li, k in enumerate(cfg["hybrid_layers"]) if k == "mamba"])
     got = {}
-    for ssd in (1, 0):
+    for ssd in (1, 2, 0):
         old = gpu.lib().nvl_set_tuning(30, ssd)
         try:
             hm = gpu.HipTransformerModel(cfg, w, precision="bf16", max_seqs=4, max_batch_tokens=512)
@@ -197,7 +198,7 @@ def test_chunked_ssd_scan_matches_oracle_and_the_sequential_scan(gpu, oracle, va
             hm.close()
         finally:
             gpu.lib().nvl_set_tuning(30, old)
-    for ssd in (1, 0):
+    for ssd in (1, 2, 0):
         a, b, st = got[ssd]
         for i in range(3):
             assert rel_err(a[i], want[i]) <= TOL["bf16"], (ssd, "prefill", i)
@@ -205,7 +206,8 @@ def test_chunked_ssd_scan_matches_oracle_and_the_sequential_scan(gpu, oracle, va
             for x, y in zip(st[i], states[i]):
                 assert rel_err(x, y) <= TOL["bf16"], (ssd, "state", i)
     # the two device forms agree much more closely with each other than either needs to with the oracle
-    assert rel_err(got[1][0], got[0][0]) <= 6e-3 and rel_err(got[1][1], got[0][1]) <= 6e-3
+    for ssd in (1, 2):
+        assert rel_err(got[ssd][0], got[0][0]) <= 6e-3 and rel_err(got[ssd][1], got[0][1]) <= 6e-3
 
 
 def test_hybrid_is_refused_where_it_cannot_work(gpu):
