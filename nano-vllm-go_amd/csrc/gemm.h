@@ -172,8 +172,16 @@ __device__ __forceinline__ float deferred_rstd(const GemmArgs& p, int m) {
     const int per = p.rs_tiles >> 2;
     const f32x4* src = (const f32x4*)(p.rs_in + (int64_t)m * p.rs_tiles + ((threadIdx.x & 63) >> 4) * per);
     f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    // only the lanes of live rows fetch: each of these loads touches one cache line per row, every epilogue wave of every
+    // workgroup issues them, and at batch 1 the 15 padding rows were 94 % of the requests queued at the L2 channels that
+    // hold these few KiB (batch 1: QKV 5.1 -> 4.6 us, FFN-up 13.3 -> 12.2 us, LM head 45.6 -> 42.8 us per launch,
+    // profiles/r03_timeline_b1_rstd.txt; the non-deferred forms take 4.1 / 12.0 / 42.2).  Rows >= M get a finite scale
+    // nobody stores with.  (Tried on top: the sums once per workgroup, coalesced, issued ahead of the weight stream — the
+    // first weight data came 0.9 us earlier and the stream took 0.9 us longer, same file.)
+    if (m < p.M) {
 #pragma unroll 8
-    for (int q = 0; q < (per >> 2); q++) a4 += src[q];
+        for (int q = 0; q < (per >> 2); q++) a4 += src[q];
+    }
     float s = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
