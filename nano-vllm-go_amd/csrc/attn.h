@@ -533,8 +533,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(const int32_t
     // (counted vmcnt) and runs, like the first QK^T MFMAs after it, while the K/V tiles are still arriving.  Round 2 waited
     // for the row with vmcnt(0) before issuing the first K load; the first round-3 order (K/V first, row behind) made the
     // RoPE and every MFMA wait for the whole K/V transfer (in-kernel stamps, scripts/decode_timeline.py: 2.3 us of compute
-    // after 6 us of transfer, nothing overlapped).  hd 128 keeps the row behind the K/V stream: 26 more live registers
-    // would spill.
+    // after 6 us of transfer, nothing overlapped).  Only the 8-wave hd-64 instantiation (GQA models at decode batches that
+    // fill the chip with one workgroup per CU) has the 26 registers to spare.
     constexpr bool ROW_FIRST = FUSED && HD == 64;
     RopeRaw rq[KS / 2], rk[KS / 2];
     f32x4 v0, v1;
@@ -551,18 +551,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(const int32_t
         const float* vrow = row + (p.nH + p.nKV + kvh) * HD + dch * 8;
         v0 = *(const f32x4*)vrow; v1 = *(const f32x4*)(vrow + 4);
     }
-    if (vw < n_kt) issue_round(vw);
-    stamps.mark(1);                     // first round's K/V loads issued
-    if (ROW_FIRST) {
-#pragma unroll
-        for (int ks = 0; ks < KS / 2; ks++) {
-            rk[ks].c0 = rq[ks].c0; rk[ks].c1 = rq[ks].c1; rk[ks].s0 = rq[ks].s0; rk[ks].s1 = rq[ks].s1;
-            rope_math8(rq[ks], cs != nullptr, qf[ks], qf[ks + KS / 2]);
-            rope_math8(rk[ks], cs != nullptr, knew[ks], knew[ks + KS / 2]);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; e++) { vnew8[e] = (bf16_t)v0[e]; vnew8[4 + e] = (bf16_t)v1[e]; }
-    } else if (FUSED) {
+    // every other instantiation: the new token's row and its rotation BEFORE the K/V stream, as in round 2 — behind it the
+    // row's temporaries are live together with the round's 32 K/V fragments (hd 64, 2 / 4 waves — MHA models: 237 -> 276
+    // registers, one wave per SIMD instead of two, GPT-2 B = 128 attention 46 -> 51 us; hd 128, 8 waves: 22 spilled)
+    if (!ROW_FIRST && FUSED) {
         const float* row = p.qkv + (int64_t)tok * p.qkv_stride;
         const float* cs2 = p.cos_t ? p.cos_t + (int64_t)pos0 * HD : nullptr;
         const float* sn = p.sin_t ? p.sin_t + (int64_t)pos0 * HD : nullptr;
@@ -575,14 +567,30 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(const int32_t
         const f32x4 w0 = *(const f32x4*)vrow, w1 = *(const f32x4*)(vrow + 4);
 #pragma unroll
         for (int e = 0; e < 4; e++) { vnew8[e] = (bf16_t)w0[e]; vnew8[4 + e] = (bf16_t)w1[e]; }
-    } else {
+    } else if (!FUSED) {
         const bf16_t* qp = (const bf16_t*)p.q + (int64_t)tok * p.q_stride + head * HD;
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) qf[ks] = *(const bf16x8*)(qp + ks * 32 + fg * 8);
     }
+    if (vw < n_kt) issue_round(vw);
+    stamps.mark(1);                     // first round's K/V loads issued
+    if (ROW_FIRST) {
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ks++) {
+            rk[ks].c0 = rq[ks].c0; rk[ks].c1 = rq[ks].c1; rk[ks].s0 = rq[ks].s0; rk[ks].s1 = rq[ks].s1;
+            rope_math8(rq[ks], cs != nullptr, qf[ks], qf[ks + KS / 2]);
+            rope_math8(rk[ks], cs != nullptr, knew[ks], knew[ks + KS / 2]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) { vnew8[e] = (bf16_t)v0[e]; vnew8[4 + e] = (bf16_t)v1[e]; }
+    }
     stamps.mark(2);                     // q/k/v of the new token rotated
-    for (int kt0 = vw; kt0 < n_kt; kt0 += NT2 * nvw) {
-        if (kt0 != vw) issue_round(kt0);
+    // one round: scores, online softmax, O^T += V^T P^T of the tiles whose K/V fragments issue_round left in kf / vch.
+    // (The first round is peeled — its loads went out above, ahead of the RoPE arithmetic — instead of making the issue
+    // conditional inside ONE loop: there every fragment register became a loop-carried value with a select per iteration,
+    // 213 -> 252 registers on the 2- and 4-wave hd-64 kernels (MHA models: one wave per SIMD instead of two) and 25
+    // spilled on the 8-wave hd-128 kernel.)
+    auto do_round = [&](int kt0) __attribute__((always_inline)) {
         // ---- scores of the round's tiles ----
         f32x4 s[NT2][4];
         float tmax = -INFINITY;
@@ -665,6 +673,11 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(const int32_t
                 }
             }
         }
+    };
+    if (vw < n_kt) do_round(vw);
+    for (int kt0 = vw + NT2 * nvw; kt0 < n_kt; kt0 += NT2 * nvw) {
+        issue_round(kt0);
+        do_round(kt0);
     }
     if (FUSED && blockIdx.z == 0 && qt == 0) {
         // append the new key/value to the slabs for the following steps — after every load of this step (which used

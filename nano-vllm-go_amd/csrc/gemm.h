@@ -711,7 +711,10 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     // their wait — a whole memory round trip, the partial sums were written by the previous kernel — and then a second
     // kernarg batch in front of the first weight load).
     const int i_pre = wave % MT;
-    const float rstd_pre = ((EPI == EPI_STORE || EPI == EPI_SWIGLU) && wave < NTW * MT) ? deferred_rstd(p, 16 * i_pre + fr) : 1.0f;   // (only the waves that run an epilogue element)
+    // (MT = 4 — batches above 32 and the 64-row groups of larger ones — has no registers to hold it across the stream:
+    // 34-54 spilled there, QKV at 128 rows 7.2 -> 10.8 us; those launches are long enough to fetch it in the epilogue)
+    constexpr bool RSTD_PRE = MT <= 2;
+    const float rstd_pre = (RSTD_PRE && (EPI == EPI_STORE || EPI == EPI_SWIGLU) && wave < NTW * MT) ? deferred_rstd(p, 16 * i_pre + fr) : 1.0f;   // (only the waves that run an epilogue element)
     // the residual operand of this wave's first epilogue element (deferred-norm producer form): fetched under the weight
     // stream, not as a dependent round trip after the K reduction (this launch is the only writer of these elements)
     f32x4 x_pre = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
         for (int i = wave; i < MT; i += NTW * ksplit) {
             const int f = (nt0 >> 1) * 16 + 4 * fg;    // NTW == 2: tiles [gate 16 | up 16] of features 8*nt0..
             epilogue_swiglu4<OutT, MOE>(p, 16 * i + fr, f, ksum(0, i), ksum(NTW - 1, i),
-                                        i == i_pre ? rstd_pre : deferred_rstd(p, 16 * i + fr));
+                                        RSTD_PRE && i == i_pre ? rstd_pre : deferred_rstd(p, 16 * i + fr));
         }
     } else if (EPI == EPI_RESID && nslices > 1) {
         // split-K across workgroups: publish the partial tile (slice 0 carries the bias); the following norm
@@ -791,9 +794,93 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
         for (int e = wave; e < NTW * MT; e += NTW * ksplit) {
             const int t = e / MT, i = e - t * MT;
             epilogue4<EPI, OutT>(p, 16 * i + fr, (nt0 + t) * 16 + 4 * fg, ksum(t, i),
-                                 EPI != EPI_STORE ? 1.0f : (i == i_pre ? rstd_pre : deferred_rstd(p, 16 * i + fr)));
+                                 EPI != EPI_STORE ? 1.0f : (RSTD_PRE && i == i_pre ? rstd_pre : deferred_rstd(p, 16 * i + fr)));
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// MoE decode routing in ONE launch (moe.go:57-103): router logits of a 16-row activation tile (E <= 64 experts, all of K),
+// softmax, top-k, renormalised weights as the dense gate matrix GemmArgs::moe_gate of the expert projections.  Before:
+// the router as a skinny GEMM launch (4.6 us) + moe_gate_kernel (4.5 us).  grid = 16-row tiles of the batch, 1024
+// threads: wave w takes expert tile w % ET over K slice w / ET (fragments straight from L2 / HBM, as the skinny kernel),
+// the K slices are summed through LDS in wave order, then wave r routes row r of the tile with a lane per expert.
+// p: A (fragment-major operand, possibly the deferred-norm raw form with rs_in), W (router, fragment-major), M, N = E, K.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void moe_router_gate_kernel(GemmArgs p, int top_k, float* __restrict__ gate, float* __restrict__ logits_out, int ld_logits) {
+    __shared__ f32x4 red[16][64];
+    __shared__ float lg[16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int E = p.N, ET = (E + 15) >> 4, KW = 16 / ET;         // expert tiles (1, 2 or 4), K slices
+    const int tile = wave % ET, kw = wave / ET;
+    const int row0 = blockIdx.x * 16;
+    const int nks = p.K >> 5, q = nks / KW, rr = nks - q * KW;
+    const int my_steps = kw < KW ? q + (kw < rr ? 1 : 0) : 0;      // (ET = 3 leaves a wave idle)
+    const int ks0 = kw * q + (kw < rr ? kw : rr);
+    const bf16_t* wp = (const bf16_t*)p.W + (((int64_t)tile * nks + ks0) * 64 + lane) * 8;
+    const bf16_t* xp = (const bf16_t*)p.A + (((int64_t)blockIdx.x * nks + ks0) * 64 + lane) * 8;
+    const bool x_live = row0 + fr < p.M;
+    const bf16x8 zero = {};
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 4 <= my_steps; s += 4) {
+        bf16x8 w[4], x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            w[u] = *(const bf16x8*)(wp + (int64_t)(s + u) * 512);
+            x[u] = x_live ? *(const bf16x8*)(xp + (int64_t)(s + u) * 512) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u], x[u], acc, 0, 0, 0);
+    }
+    for (; s < my_steps; s++)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(wp + (int64_t)s * 512), x_live ? *(const bf16x8*)(xp + (int64_t)s * 512) : zero, acc, 0, 0, 0);
+    // deferred RMSNorm: wave r owns row r of the tile — its x^2 partials, a lane per 16-byte chunk
+    float ssq = 0.f;
+    if (p.rs_in && row0 + wave < p.M) {
+        const f32x4* src = (const f32x4*)(p.rs_in + (int64_t)(row0 + wave) * p.rs_tiles);
+        f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = lane; c < (p.rs_tiles >> 2); c += 64) a4 += src[c];
+        ssq = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) ssq += __shfl_xor(ssq, o, 64);
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave < ET) {        // acc of lane (fr, fg): row fr, experts 16 tile + 4 fg .. + 3
+        f32x4 v = red[wave][lane];
+        for (int k = 1; k < KW; k++) v += red[k * ET + wave][lane];
+#pragma unroll
+        for (int r = 0; r < 4; r++) lg[fr][16 * wave + 4 * fg + r] = v[r];
+    }
+    __syncthreads();
+    const int m = row0 + wave;
+    if (m >= p.M) return;
+    const float rstd = p.rs_in ? 1.0f / sqrtf(ssq * p.rs_inv_h + p.rs_eps) : 1.0f;
+    const float v = (lane < E) ? lg[wave][lane] * rstd : -INFINITY;
+    if (logits_out && lane < E) logits_out[(int64_t)m * ld_logits + lane] = v;
+    float mx = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float e = (lane < E) ? expf(v - mx) : 0.f;
+    float sum = e;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) sum += __shfl_xor(sum, o, 64);
+    const float prob = (lane < E) ? e / sum : -1.f;
+    int rank = 0;                                   // larger first, ties to the lower index (moe.go:75-92)
+    const int pbits = __builtin_bit_cast(int, prob);
+#pragma unroll 8
+    for (int j = 0; j < E; j++) {                   // (lanes >= E hold -1: they never outrank an expert)
+        const float pj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pbits, j));
+        rank += (pj > prob || (pj == prob && j < lane)) ? 1 : 0;
+    }
+    float wsum = 0.f;
+    for (int k = 0; k < top_k; k++) {               // moe.go:89-92: fp32 sum in rank order
+        const int src = __ffsll((unsigned long long)__ballot(rank == k)) - 1;
+        wsum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(pbits, src));
+    }
+    if (lane < E) gate[(int64_t)m * E + lane] = rank < top_k ? prob / wsum : 0.f;      // moe.go:103
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1254,7 +1254,9 @@ void tp_allreduce(nvl_model* m, float* buf, int64_t count) {
 
 static int g_half_tiles = 1;   // nvl_set_tuning key 27: deferred-norm residual projections of <= 16 rows on 8-row half tiles (gemm.h HALF)
 // (producer and consumer agree through M alone: every projection of a pass has the same row count)
-bool defer_half(const nvl_model* m, int M) { return g_half_tiles && M <= 16 && m->H % 128 == 0; }
+// (only while the 16-row tiles leave CUs idle: at H = 4096 — 256 tiles — the halves doubled the x^2 partials every consumer
+// sums and the workgroups that each fetch the activations: Llama-3-8B B = 16 FFN-down 23.7 -> 34.2 us, O 9.3 -> 12.4 us)
+bool defer_half(const nvl_model* m, int M) { return g_half_tiles && M <= 16 && m->H % 128 == 0 && m->H / 16 < 256; }
 // after a forward's stream sync: did a P2P wait give up?  (a peer died or never called: the residual stream is garbage)
 void p2p_check(nvl_model* m) {
     if (!m->p2p_ready) return;
@@ -1298,6 +1300,7 @@ static int g_moe_dense = 1;    // nvl_set_tuning key 22: decode MoE as two dense
 static int g_moe_deep = 1;     // nvl_set_tuning key 19: four-stage grouped GEMM for decode-sized MoE batches (0 = two stages)
 static int g_moe_bm = 0;       // nvl_set_tuning key 17: prefill MoE grouped GEMMs: 0 = 256-row tiles on the ping-pong kernel, 128 / 256 = the lock-step tile kernels
 static int g_moe_gather = 1;   // nvl_set_tuning key 16: prefill MoE gathers the token rows into expert order before the grouped GEMM (0 = per-lane gather inside it)
+static int g_moe_fused_route = 1;   // nvl_set_tuning key 31: MoE decode routing (router GEMM + softmax / top-k / gate matrix) as one launch (0 = two)
 static int g_moe_small = 1;    // nvl_set_tuning key 8: fused MoE planning launch + combine folded into the next norm (0 = off)
 static int g_mamba_ssd = 1;    // nvl_set_tuning key 30: chunked (SSD) Mamba2 scan on MFMA for prefill-sized bf16 calls (0 = the sequential scan,
                                // 2 = chunk after chunk only, never the chunk-parallel three-launch form)
@@ -1349,6 +1352,9 @@ void resid_gemm(nvl_model* m, const void* A, int lda, const void* W, const float
         N % 128 == 0 && K % 64 == 0 && norm_ok && N == m->H && g_force_tile == 0 && m->n_mamba == 0) {
         const int tiles = cdiv(M, 128) * (N / 128);
         while (slices < SK_TILE_MAX_SLICES && tiles * slices < 512 && K / (slices * 2) >= 512) slices *= 2;
+        // (fewer than 64 workgroups even so — GPT-2's 768 columns below 512 rows —: the decode form's 64-row groups stream
+        // better, profiles/r03_gpt2_large_decode_batches.txt: B = 128 147.5 K -> 159.0 K, B = 256 224.8 K -> 237.2 K tok/s)
+        if (tiles * slices < 64) slices = 1;
     }
     if (slices > 1) {
         a.sk_part = m->sk_part; a.sk_slices = slices;
@@ -1403,18 +1409,27 @@ void moe(nvl_model* m, const LayerW& l, int M, bool deferred_norm = false) {
     // algorithmic weight bytes of the expert GEMMs: the experts a batch of `pairs` (token, rank) pairs can touch, once
     const double e_touch = (double)std::min(E, pairs);
     m->site = KS_MOE_ROUTER;
+    const bool dense = moe_dense_ok(m, l, M) && m->pending_slices == 0;
+    // decode: router logits, softmax, top-k and the dense gate matrix in one launch (gemm.h moe_router_gate_kernel)
+    const bool fused_route = dense && g_moe_fused_route && E <= 64 && H % 32 == 0;
     {
         GemmArgs ar = mk(m->xn, H, l.t[NVL_T_ROUTER].p, m->router_logits, 128, nullptr, 1.f, M, E, H);
         if (deferred_norm) set_deferred_in(m, ar);
-        gemm(m, EPI_STORE, true, ar);
+        if (fused_route) {
+            KScope ks(m, KC_GEMM, 2.0 * (double)M * E * H, -1, ((double)E * H + (double)M * H) * (double)m->wsize + (double)M * E * 8.0);
+            hipLaunchKernelGGL(moe_router_gate_kernel, dim3(cdiv(M, 16)), dim3(1024), 0, m->stream, ar, k, m->moe_gate, m->router_logits, 128);
+            NVL_HIP(hipGetLastError());
+        } else {
+            gemm(m, EPI_STORE, true, ar);
+        }
     }
     // Decode: the dense-masked form (gemm.h GemmArgs::moe_gate).  Routing weights as a dense [M][E] matrix, then all experts
     // as ONE weight-streaming projection each way; untouched experts are skipped inside the kernels, the gate weight in the up
     // epilogue turns the down projection's K reduction into the weighted combine, its K slices are summed by the next norm.
-    if (deferred_norm && !(moe_dense_ok(m, l, M) && m->pending_slices == 0))
+    if (deferred_norm && !dense)
         throw std::runtime_error("moe: a deferred FFN norm needs the dense-masked decode form");
-    if (moe_dense_ok(m, l, M) && m->pending_slices == 0) {
-        {
+    if (dense) {
+        if (!fused_route) {
             KScope ks(m, KC_OTHER, 0, KS_MOE_PLAN, (double)M * (128 + E) * 4.0);
             hipLaunchKernelGGL(moe_gate_kernel, dim3(cdiv(M, 4)), dim3(256), 0, m->stream, m->router_logits, 128, M, E, k, m->moe_gate);
             NVL_HIP(hipGetLastError());

@@ -423,5 +423,6 @@ extern "C" int nvl_set_tuning(int key, int value) {
     if (key == 27) { const int old = g_half_tiles; g_half_tiles = value; return old; }
     if (key == 29) { const int old = g_p2p_spin_ms; g_p2p_spin_ms = value; return old; }
     if (key == 30) { const int old = g_mamba_ssd; g_mamba_ssd = value; return old; }
+    if (key == 31) { const int old = g_moe_fused_route; g_moe_fused_route = value; return old; }
     return -1;
 }

@@ -353,6 +353,41 @@ def test_graph_replayed_decode_is_bit_identical_to_eager(gpu, oracle, family):
     hm.close()
 
 
+def test_moe_decode_routing_one_launch_matches_two(gpu, oracle):
+    """MoE decode routing (moe.go:57-103): gemm.h moe_router_gate_kernel — router logits, softmax, top-k and the dense gate
+    matrix in one launch — against the router as its own skinny GEMM followed by moe_gate_kernel (tuning key 31 = 0).  The
+    two sum the router's K slices in a different order (fp32), so the logits agree to rounding, not bit for bit; both sit
+    inside the oracle tolerance.  Batches of 3 (one ragged 16-row tile) and 20 (two tiles)."""
+    cfg, om, hm = build(gpu, oracle, "granite_moe", "bf16")
+    r = np.random.default_rng(131)
+    for nseq in (3, 20):
+        hm2 = gpu.HipTransformerModel(cfg, gpu.synth.make_weights(cfg, seed=7, scale=0.05), precision="bf16", max_seqs=nseq,
+                                      max_batch_tokens=512) if nseq > 4 else hm
+        ids = list(range(nseq))
+        prompts = [r.integers(0, cfg["vocab_size"], int(n)).tolist() for n in r.integers(5, 24, nseq)]
+        forced = [int(t) for t in r.integers(0, cfg["vocab_size"], nseq)]
+        got = {}
+        for fused in (1, 0):
+            old = gpu.lib().nvl_set_tuning(31, fused)
+            try:
+                for i in ids:
+                    hm2.seq_reset(i)
+                hm2.forward_batch(ids, prompts, [0] * nseq, want_logits=False)
+                got[fused], _ = hm2.forward_batch(ids, [[t] for t in forced], [len(p) for p in prompts])
+            finally:
+                gpu.lib().nvl_set_tuning(31, old)
+        assert rel_err(got[1], got[0]) <= 2e-3, nseq
+        if nseq <= 4:
+            for i in ids:
+                kv = om.new_cache()
+                om.forward_with_cache(prompts[i], kv, 0)
+                want = om.forward_with_cache([forced[i]], kv, len(prompts[i]))[-1]
+                assert rel_err(got[1][i], want) <= TOL["bf16"] and rel_err(got[0][i], want) <= TOL["bf16"]
+        if hm2 is not hm:
+            hm2.close()
+    hm.close()
+
+
 def test_fused_loop_graph_survives_a_longer_second_call(gpu, oracle):
     """nvl_decode_greedy keeps its step tokens in a device ring that grows with n_steps x n_seqs; the captured step graph
     holds the ring's address as a kernel argument, so growing the ring must drop the captured graphs (round-2 advisor
