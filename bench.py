@@ -319,17 +319,19 @@ def main():
         for fn in sorted(os.listdir(cdir)):
             if fn.endswith((".h", ".hip")):
                 h.update(fn.encode()); h.update((cdir / fn).read_bytes())
-        pmc = json.load(open(ROOT / "profiles" / "r02_pmc_traffic.json"))
+        pmc_files = sorted((ROOT / "profiles").glob("r[0-9][0-9]_pmc_traffic.json"), reverse=True)     # newest round first
+        pmc_name = f"profiles/{pmc_files[0].name}"
+        pmc = json.load(open(pmc_files[0]))
         if pmc.get("kernel_src_sha16") != h.hexdigest()[:16]:
-            traffic_note = "profiles/r02_pmc_traffic.json was taken on a different kernel source: refused"
+            traffic_note = f"{pmc_name} was taken on a different kernel source: refused"
         elif not (args.model == "llama-3.2-1b" and (B, S) == (32, 512) and args.precision == "bf16" and not tp):
-            traffic_note = "profiles/r02_pmc_traffic.json is for llama-3.2-1b 32 x 512 bf16: refused for this workload"
+            traffic_note = f"{pmc_name} is for llama-3.2-1b 32 x 512 bf16: refused for this workload"
         else:
             site_traffic = {k: round(v["hbm_bytes_per_launch"]) for k, v in pmc["sites"].items()}
             gs = [v for k, v in pmc["sites"].items() if k in ("prefill/qkv_proj", "prefill/o_proj", "prefill/ffn_up", "prefill/ffn_down")]
             traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in gs) / max(1, sum(v["launches"] for v in gs)))
             traffic_note = ("bytes/launch past L2 (Infinity-Cache hits included), prefill projection class, "
-                            "profiles/r02_pmc_traffic.json (same kernel source hash)")
+                            f"{pmc_name} (same kernel source hash)")
     except Exception as e:      # noqa: BLE001
         traffic, site_traffic = None, {}
         traffic_note = f"no usable PMC profile ({type(e).__name__})"
@@ -360,7 +362,7 @@ def main():
         "kernels_note": "per launch site, from ONE extra profiled step after the timed region (HIP events around every launch on the "
                         "library's stream; avg_launch_us is the event INTERVAL, which includes the bracket itself — about 2-3 us on this box, "
                         "so the entries of 5-20 us decode kernels understate their rates; rocprofv3's per-kernel durations of the same "
-                        "command are in profiles/r02_bench_kernel_stats.csv / r02_phase_breakdown_b32.txt); work = algorithmic flops / bytes (weights once + operands + results; attention: every cached "
+                        "command are in profiles/r03_bench_kernel_stats.csv / r03_phase_breakdown_b32.txt); work = algorithmic flops / bytes (weights once + operands + results; attention: every cached "
                         "K/V once); frac vs 2.5 PFLOP/s (mfma) or 8 TB/s (hbm)",
         "dominant_by_time": (max(kernels, key=lambda e: e["share_of_step"]) if kernels else None),
         "load_s": round(t_load, 1),

@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define NVL_ABI_VERSION 2      /* 2: Mamba2 / hybrid layers (config fields, tensor kinds), nvl_stats.evictions, kernel stats */
+#define NVL_ABI_VERSION 3      /* 2: Mamba2 / hybrid layers (config fields, tensor kinds), nvl_stats.evictions, kernel stats;
+                                  3: nvl_get_weight, nvl_get_stamps, nvl_tp_p2p_rearm, debug modes 2 / 4 (additions only) */
 
 typedef enum nvl_status {
     NVL_OK = 0,

@@ -12,7 +12,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(names) >= 30 and "nvl_forward" in names and "nvl_runner_run" in names
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.nvl_abi_version() == 2
+    assert L.nvl_abi_version() == 3
 
 
 def test_header_cites_the_reference_for_every_entry_point(pkg):
