@@ -266,7 +266,11 @@ int nvl_get_hidden(nvl_model* m, int layer, float* out, int64_t n_floats);
  * (eager launches, no graph replay) record, per workgroup, the chip's 100 MHz constant clock at six points of their life —
  * entered / first loads issued / first data used / own stream done / workgroup's stream done / stores retired.
  * nvl_get_stamps returns the launches recorded so far: recs[3 i] = {site (nvl_kernel_site_name), phase, workgroups}, and the
- * stamps [workgroups][8] of the launches back to back.  scripts/decode_timeline.py prints the step's timeline from them. */
+ * stamps [workgroups][8] of the launches back to back.  scripts/decode_timeline.py prints the step's timeline from them.
+ * Only in the diagnostic build of the library (make -C csrc diag -> libnvllm_hip_diag.so, -DNVL_STAMPS): the product library
+ * has no stamp sites — compiled in and disabled they cost 3-7 % per decode projection — and answers mode 4 with
+ * NVL_ERR_STATE.  The stamps perturb what they time (they pin the instruction schedule around them): use them to see where a
+ * launch waits, and the kernel trace of the product build to decide whether a change paid. */
 int nvl_get_stamps(nvl_model* m, int32_t* recs, int rec_cap, uint64_t* stamps, int64_t stamp_cap);
 /* Debug/parity: copy a sequence's cache for one layer as the reference lays it out,
  * K and V each [nKV, T, hd] fp32 (kv_cache.go:5-6).  Returns T. */

@@ -3,11 +3,13 @@ missing this module raises, and if no GPU is visible every compute call returns 
 from __future__ import annotations
 
 import ctypes as C
+import os
 import re
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "lib" / "libnvllm_hip.so"
+# NVLLM_LIB: another build of the same library (the diagnostic build libnvllm_hip_diag.so of csrc/Makefile's `diag` target)
+LIB_PATH = Path(os.environ["NVLLM_LIB"]).resolve() if os.environ.get("NVLLM_LIB") else _PKG / "lib" / "libnvllm_hip.so"
 HEADER = _PKG.parent / "include" / "nvllm.h"
 
 SLOTS = [

@@ -693,8 +693,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(const int32_t
             *(bf16x8*)((bf16_t*)p.vcache + noff + dch * 8) = vnew8;
     }
     // ---- flash-decoding combine through LDS (the partial O^T overwrites this wave's own V image), fixed wave order ----
-    asm volatile("" :: "v"(o[0]));
-    stamps.mark(3);                     // wave 0's tiles done
+    stamps.mark_used(3, o[0]);          // wave 0's tiles done
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     if (fg == 0) { red_m[wave][fq] = m_run; red_l[wave][fq] = l_run; }

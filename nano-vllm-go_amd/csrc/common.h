@@ -102,6 +102,17 @@ __device__ __forceinline__ float wave_max(float v) {
 // The times are kept in registers and written when the object dies (the kernel's exits): a store to global memory at the
 // top of a kernel would make every later uniform load a vector load (the compiler may no longer assume the loaded
 // memory unclobbered, so it cannot use the scalar cache) — the instrumentation would change what it measures.
+#ifndef NVL_STAMPS
+// the product library: no stamp site at all.  (Round 3 first shipped the sites compiled in and disabled by a NULL buffer:
+// each one still is a branch with two scheduling barriers inside, which splits the kernel's scheduling regions — every
+// decode projection ran 3-7 % slower than in round 2, 31.0 K against 32.1 K decode tok/s at B = 32 on the same box,
+// profiles/r03_ab_stamp_sites.txt.)  `make diag` builds libnvllm_hip_diag.so with -DNVL_STAMPS for scripts/decode_timeline.py.
+struct NvlStamps {
+    __device__ __forceinline__ NvlStamps(unsigned long long*, int) {}
+    __device__ __forceinline__ void mark(int) {}
+    template <typename T> __device__ __forceinline__ void mark_used(int, const T&) {}
+};
+#else
 struct NvlStamps {
     unsigned long long* buf; int wg; unsigned long long t[6];
     __device__ __forceinline__ NvlStamps(unsigned long long* b, int w) : buf(b), wg(w) {
@@ -120,6 +131,8 @@ struct NvlStamps {
             t[slot] = v;
         }
     }
+    // stamp once `v` has been computed (pins the stamp behind the instructions that produce it)
+    template <typename T> __device__ __forceinline__ void mark_used(int slot, const T& v) { asm volatile("" :: "v"(v)); mark(slot); }
     __device__ __forceinline__ ~NvlStamps() {
         if (!buf) return;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores are retired
@@ -130,13 +143,15 @@ struct NvlStamps {
         }
     }
 };
+#endif
 // compile-time switch for kernels with uniform global loads (decode attention): even a disabled stamp site is an opaque
 // side effect to the compiler, after which uniform loads may no longer use the scalar path
 template <bool ON> struct NvlStampsT;
-template <> struct NvlStampsT<true> : NvlStamps { using NvlStamps::NvlStamps; };
+template <> struct NvlStampsT<true> : NvlStamps { __device__ __forceinline__ NvlStampsT(unsigned long long* b, int w) : NvlStamps(b, w) {} };
 template <> struct NvlStampsT<false> {
     __device__ __forceinline__ NvlStampsT(unsigned long long*, int) {}
     __device__ __forceinline__ void mark(int) {}
+    template <typename T> __device__ __forceinline__ void mark_used(int, const T&) {}
 };
 constexpr int STAMP_MAX_WG = 2048, STAMP_MAX_LAUNCH = 128;
 

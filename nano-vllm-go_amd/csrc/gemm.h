@@ -653,6 +653,16 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     // K/32 k-steps dealt over (gridDim.y slices) x (ksplit waves) as evenly as possible (K need not divide:
     // Falcon's 4544 = 142 steps)
     const int i_off = p.m_split ? blockIdx.y : 0;                  // first 16-row activation tile of this workgroup
+    // deferred RMSNorm (consumer side): the scale of the rows of this wave's first epilogue element, fetched under the weight
+    // stream instead of after it.  Issued HERE, ahead of the first weight block.  (Round 3 moved it behind the first block on
+    // the evidence of in-kernel time stamps — first weight data 0.5 us earlier — and lost 0.5 us per QKV launch and 0.25 us
+    // per FFN-up launch at B = 32 by the kernel trace of the unstamped build: the stamp sites themselves had changed the
+    // schedule they measured.  profiles/r03_ab_vs_r02.txt)
+    const int i_pre = wave % MT;
+    // (MT = 4 — batches above 32 and the 64-row groups of larger ones — has no registers to hold it across the stream:
+    // 34-54 spilled there, QKV at 128 rows 7.2 -> 10.8 us; those launches are long enough to fetch it in the epilogue)
+    constexpr bool RSTD_PRE = MT <= 2;
+    const float rstd_pre = (RSTD_PRE && (EPI == EPI_STORE || EPI == EPI_SWIGLU) && wave < NTW * MT) ? deferred_rstd(p, 16 * i_pre + fr) : 1.0f;   // (only the waves that run an epilogue element)
     // (grid_y: gridDim.y as an explicit argument — the built-in lives in the hidden part of the kernarg block and costs a
     // dependent scalar round trip of its own before the first weight load)
     const int nslices = p.m_split ? 1 : p.grid_y, slice = p.m_split ? 0 : blockIdx.y;
@@ -706,15 +716,6 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     };
     if (nblk > 0) load_blk(wA, xA, 0);
     stamps.mark(1);                     // first block of loads issued
-    // deferred RMSNorm (consumer side): the scale of the rows of this wave's first epilogue element.  Its loads are issued
-    // HERE, behind the first block of the weight stream (round 2 had them at the top of the kernel, where the compiler put
-    // their wait — a whole memory round trip, the partial sums were written by the previous kernel — and then a second
-    // kernarg batch in front of the first weight load).
-    const int i_pre = wave % MT;
-    // (MT = 4 — batches above 32 and the 64-row groups of larger ones — has no registers to hold it across the stream:
-    // 34-54 spilled there, QKV at 128 rows 7.2 -> 10.8 us; those launches are long enough to fetch it in the epilogue)
-    constexpr bool RSTD_PRE = MT <= 2;
-    const float rstd_pre = (RSTD_PRE && (EPI == EPI_STORE || EPI == EPI_SWIGLU) && wave < NTW * MT) ? deferred_rstd(p, 16 * i_pre + fr) : 1.0f;   // (only the waves that run an epilogue element)
     // the residual operand of this wave's first epilogue element (deferred-norm producer form): fetched under the weight
     // stream, not as a dependent round trip after the K reduction (this launch is the only writer of these elements)
     f32x4 x_pre = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -727,7 +728,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     for (; b + 2 <= nblk; b += 2) {
         load_blk(wB, xB, b + 1);
         comp_blk(wA, xA);
-        if (b == 0) { asm volatile("" :: "v"(acc[0])); stamps.mark(2); }   // first block's data arrived and was used
+        if (b == 0) stamps.mark_used(2, acc[0]);       // first block's data arrived and was used
         if (b + 2 < nblk) load_blk(wA, xA, b + 2);
         comp_blk(wB, xB);
     }
@@ -980,6 +981,10 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
     const int my_steps = q + (kw < rr ? 1 : 0);
     const int ks0 = kw * q + (kw < rr ? kw : rr);
     const int64_t tile_stride = (int64_t)nks * 512;  // elements between consecutive 16-row weight tiles
+    // deferred RMSNorm: the scale of the rows this wave's epilogue elements belong to, fetched under the weight stream
+    // (ahead of the first weight block: see the narrow kernel)
+    const int i_pre = kw % MT;
+    const float rstd_pre = (EPI == EPI_SWIGLU || EPI == EPI_STORE) ? deferred_rstd(p, 16 * i_pre + fr) : 1.0f;
     const bf16_t* wp = (const bf16_t*)p.W + (((int64_t)nt0 * nks + ks0) * 64 + lane) * 8;
     const bf16_t* xp = (const bf16_t*)p.A + ((int64_t)ks0 * 64 + lane) * 8;
     f32x4 acc[NTB][MT];
@@ -1013,15 +1018,11 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_bf16_kernel(GemmArgs p) 
     };
     if (nblk > 0) load_blk(wA, xA, 0);
     stamps.mark(1);
-    // deferred RMSNorm: the scale of the rows this wave's epilogue elements belong to; its loads go out behind the first
-    // block of the weight stream (not in front of it: see the narrow kernel)
-    const int i_pre = kw % MT;
-    const float rstd_pre = (EPI == EPI_SWIGLU || EPI == EPI_STORE) ? deferred_rstd(p, 16 * i_pre + fr) : 1.0f;
     int b = 0;
     for (; b + 2 <= nblk; b += 2) {
         load_blk(wB, xB, b + 1);
         comp_blk(wA, xA);
-        if (b == 0) { asm volatile("" :: "v"(acc[0][0])); stamps.mark(2); }
+        if (b == 0) stamps.mark_used(2, acc[0][0]);
         if (b + 2 < nblk) load_blk(wA, xA, b + 2);
         comp_blk(wB, xB);
     }

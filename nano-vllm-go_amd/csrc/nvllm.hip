@@ -2330,6 +2330,12 @@ extern "C" int nvl_set_debug(nvl_model* m, int keep_hidden) {
     m->keep_hidden = keep_hidden == 1;      // 1: per-layer residual stream, every residual add completed in its own launch
     m->tap = keep_hidden == 2;              // 2: the same record taken beside the unmodified product path (pending adds included)
     m->stamping = keep_hidden == 4;         // 4: in-kernel time stamps of the decode kernels (nvl_get_stamps), eager launches
+#ifndef NVL_STAMPS
+    if (m->stamping) {      // the product library carries no stamp sites (common.h NvlStamps): the diagnostic build does
+        m->stamping = false;
+        return fail(m, NVL_ERR_STATE, "nvl_set_debug: mode 4 needs the diagnostic build (make -C csrc diag -> libnvllm_hip_diag.so, NVLLM_LIB)");
+    }
+#endif
     if (m->stamping) {
         NVL_TRY(m)
         NVL_HIP(hipSetDevice(m->device));

@@ -8,6 +8,7 @@ maximum over workgroups of each phase.  usage (GPU box): decode_timeline.py [--b
 import argparse
 import ctypes as C
 import importlib
+import os
 import sys
 from pathlib import Path
 
@@ -15,6 +16,8 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+# the diagnostic build (make -C nano-vllm-go_amd/csrc diag): the product library has no stamp sites
+os.environ.setdefault("NVLLM_LIB", str(ROOT / "nano-vllm-go_amd" / "lib" / "libnvllm_hip_diag.so"))
 
 
 def main():
