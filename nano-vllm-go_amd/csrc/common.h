@@ -106,7 +106,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // the product library: no stamp site at all.  (Round 3 first shipped the sites compiled in and disabled by a NULL buffer:
 // each one still is a branch with two scheduling barriers inside, which splits the kernel's scheduling regions — every
 // decode projection ran 3-7 % slower than in round 2, 31.0 K against 32.1 K decode tok/s at B = 32 on the same box,
-// profiles/r03_ab_stamp_sites.txt.)  `make diag` builds libnvllm_hip_diag.so with -DNVL_STAMPS for scripts/decode_timeline.py.
+// profiles/r03_ab_vs_r02.txt.)  `make diag` builds libnvllm_hip_diag.so with -DNVL_STAMPS for scripts/decode_timeline.py.
 struct NvlStamps {
     __device__ __forceinline__ NvlStamps(unsigned long long*, int) {}
     __device__ __forceinline__ void mark(int) {}
