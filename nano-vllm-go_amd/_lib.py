@@ -5,6 +5,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import re
+import sys
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
@@ -112,6 +113,15 @@ def lib():
     if not LIB_PATH.exists():
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64, this library links /opt/rocm's.  Whichever is
+    # loaded first owns the device; loaded second, torch then finds "no ROCm-capable device" (seen on the GPU box when a test
+    # touched the library before its first `import torch`).  If torch is installed, load it first — both then share its runtime,
+    # which is the order every script here already used.  The library itself never needs torch.
+    if "torch" not in sys.modules and not os.environ.get("NVLLM_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(str(LIB_PATH))
     L.nvl_create.argtypes = [C.POINTER(ModelConfigC), C.POINTER(RuntimeOptsC), C.POINTER(vp)]
     L.nvl_upload_tensor.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, i64, i64, C.c_int]

@@ -670,9 +670,29 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
     const int nks = p.K >> 5, q = nks / nparts, rr = nks - q * nparts;
     int my_steps = q + (part < rr ? 1 : 0);
     const int ks0 = part * q + (part < rr ? part : rr);   // first k-step of this wave
-    if constexpr (MOE) {   // MoE decode (its own instantiation): stream only the experts some token of the batch picked
+    // MoE decode (its own instantiation): stream only the experts some token of the batch picked.  Up: a workgroup's rows
+    // belong to one expert.  Down: a wave's K range covers up to four experts (one with the K split over workgroups, two
+    // to four in the deferred-norm form, which keeps all of K in one workgroup); blk_live bit b = block b (U k-steps,
+    // inside one expert: the launcher checks the divisibility) of this wave's range is to be streamed.
+    uint32_t blk_live = 0xffffffffu;
+    bool tail_live = true;                 // the ragged tail (fewer than U k-steps; it lies inside the range's last expert)
+    if constexpr (MOE) {
         if (EPI == EPI_SWIGLU) { if (!moe_expert_live(p, (nt0 * 16) / (2 * p.moe_I))) return; }          // (whole workgroup: uniform)
-        else if (!moe_expert_live(p, (ks0 * 32) / p.moe_I)) my_steps = 0;                                 // this wave adds zero
+        else {
+            const int spe = p.moe_I >> 5, e0 = ks0 / spe, e1 = (ks0 + my_steps - 1) / spe;      // k-steps per expert; this wave's experts
+            float g[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) g[j] = (e0 + j <= e1 && lane < p.M) ? p.moe_gate[lane * p.moe_E + e0 + j] : 0.f;   // (one round trip for all four)
+            blk_live = 0;
+            tail_live = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (!__any(g[j] != 0.f)) continue;
+                if (e0 + j == e1) tail_live = true;
+                const int b0 = max(((e0 + j) * spe - ks0) / U, 0), b1 = min(((e0 + j + 1) * spe - ks0) / U, 32);
+                if (b1 > b0) blk_live |= (b1 - b0 >= 32 ? 0xffffffffu : ((1u << (b1 - b0)) - 1u)) << b0;
+            }
+        }
     }
 
     const bf16_t* wp = (const bf16_t*)p.W + (((int64_t)(nt0 + tile) * (p.K >> 5) + ks0) * 64 + lane) * 8;
@@ -714,16 +734,36 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
             for (int i = 0; i < MT; i++)
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u], x[u][i], acc[i], 0, 0, 0);
     };
-    if (nblk > 0) load_blk(wA, xA, 0);
+    // MoE down: the live blocks of the wave's range, in order, through the same two register sets
+    uint32_t live = 0;
+    int bA = -1;
+    if constexpr (MOE && EPI == EPI_RESID) {
+        live = blk_live & (nblk >= 32 ? 0xffffffffu : ((1u << nblk) - 1u));
+        live = __builtin_amdgcn_readfirstlane(live);
+        if (live) { bA = __builtin_ctz(live); live &= live - 1; load_blk(wA, xA, bA); }
+    } else {
+        if (nblk > 0) load_blk(wA, xA, 0);
+    }
     stamps.mark(1);                     // first block of loads issued
     // the residual operand of this wave's first epilogue element (deferred-norm producer form): fetched under the weight
     // stream, not as a dependent round trip after the K reduction (this launch is the only writer of these elements)
     f32x4 x_pre = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (EPI == EPI_RESID && !MOE && p.rs_out && wave < NTW * MT) {
+    if (EPI == EPI_RESID && p.rs_out && wave < NTW * MT) {
         const int t = wave / MT, i = wave - t * MT;
         const int m = 16 * (i + i_off) + fr, n = (nt0 + t) * 16 + 4 * fg;
         if (m < p.M && n < p.N && (!HALF || (fg >> 1) == half)) x_pre = *(const f32x4*)((const float*)p.C + (int64_t)m * p.ldc + n);
     }
+    if constexpr (MOE && EPI == EPI_RESID) {
+        while (bA >= 0) {
+            int bB = -1;
+            if (live) { bB = __builtin_ctz(live); live &= live - 1; load_blk(wB, xB, bB); }
+            comp_blk(wA, xA);
+            if (bB < 0) break;
+            bA = -1;
+            if (live) { bA = __builtin_ctz(live); live &= live - 1; load_blk(wA, xA, bA); }
+            comp_blk(wB, xB);
+        }
+    } else {
     int b = 0;
     for (; b + 2 <= nblk; b += 2) {
         load_blk(wB, xB, b + 1);
@@ -733,7 +773,8 @@ __global__ __launch_bounds__(1024) void gemm_skinny_bf16_kernel(GemmArgs p) {
         comp_blk(wB, xB);
     }
     if (b < nblk) comp_blk(wA, xA);
-    for (int s = nblk * U; s < my_steps; s++) {      // ragged tail: fewer than U k-steps
+    }
+    for (int s = nblk * U; s < (tail_live ? my_steps : 0); s++) {      // ragged tail: fewer than U k-steps
         const bf16x8 w = w_live ? weight_load<PASSES>((const bf16x8*)(wp + (int64_t)s * 512)) : x_zero;
 #pragma unroll
         for (int i = 0; i < MT; i++)
@@ -1124,6 +1165,20 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
         while (ks > 1 && (a.K >> 5) / ks < 4) ks >>= 1;
         if (a.K % 32 != 0) return false;
         if constexpr (EPI == EPI_RESID) {
+            if (a.moe_gate) {     // MoE down as the deferred-norm producer: all experts in one workgroup's K range, 16 waves
+                ks = 16;
+                const int nks = a.K >> 5, spe = a.moe_I >> 5;
+                if (nks % (ks * 4) != 0 || spe % 4 != 0 || nks / ks > 4 * spe || nks / ks / 4 > 32) return false;
+                if (a.rs_half) {
+                    if (a.M > 16) return false;
+                    hipLaunchKernelGGL((gemm_skinny_bf16_kernel<1, NTW, 4, EPI, OutT, false, true, true>), dim3(2 * nblocks, 1), dim3(NTW * ks * 64),
+                                       (size_t)NTW * ks * 64 * 16, st, a);
+                } else {
+                    hipLaunchKernelGGL((gemm_skinny_bf16_kernel<1, NTW, 4, EPI, OutT, false, true>), dim3(nblocks, cdiv(a.M, 16)), dim3(NTW * ks * 64),
+                                       (size_t)NTW * ks * 64 * 16, st, a);
+                }
+                return true;
+            }
             if (a.rs_half) {      // <= 16 rows: 8 weight rows per workgroup, twice the workgroups (HALF above)
                 if (a.M > 16) return false;
                 hipLaunchKernelGGL((gemm_skinny_bf16_kernel<1, NTW, 4, EPI, OutT, false, false, true>), dim3(2 * nblocks, 1), dim3(NTW * ks * 64),

@@ -1300,6 +1300,10 @@ static int g_moe_dense = 1;    // nvl_set_tuning key 22: decode MoE as two dense
 static int g_moe_deep = 1;     // nvl_set_tuning key 19: four-stage grouped GEMM for decode-sized MoE batches (0 = two stages)
 static int g_moe_bm = 0;       // nvl_set_tuning key 17: prefill MoE grouped GEMMs: 0 = 256-row tiles on the ping-pong kernel, 128 / 256 = the lock-step tile kernels
 static int g_moe_gather = 1;   // nvl_set_tuning key 16: prefill MoE gathers the token rows into expert order before the grouped GEMM (0 = per-lane gather inside it)
+static int g_moe_defer_down = 0;    // nvl_set_tuning key 33: MoE decode: the down projection carries the next norm (deferred RMSNorm producer: all of
+                                    // K in one workgroup, one launch less per layer) instead of K slices + a norm launch.  Off: with 128 workgroups of
+                                    // 16 waves each wave walks 8 blocks (two experts) instead of 4 — Granite-1B B=8 down projection 8.9 -> 14.5 us, more
+                                    // than the norm launch it saves: 6.48 K -> 6.26 K decode tok/s (profiles/r03_moe_decode_experiments.txt)
 static int g_moe_fused_route = 1;   // nvl_set_tuning key 31: MoE decode routing (router GEMM + softmax / top-k / gate matrix) as one launch (0 = two)
 static int g_moe_small = 1;    // nvl_set_tuning key 8: fused MoE planning launch + combine folded into the next norm (0 = off)
 static int g_mamba_ssd = 1;    // nvl_set_tuning key 30: chunked (SSD) Mamba2 scan on MFMA for prefill-sized bf16 calls (0 = the sequential scan,
@@ -1402,7 +1406,10 @@ bool moe_dense_ok(const nvl_model* m, const LayerW& l, int M) {
 }
 // deferred_norm: m->xn holds xn_raw = bf16(x * w_norm) and m->rs_part the x^2 partials (the O projection carried the FFN
 // norm): the router and the expert-up projection scale their accumulators by rstd[m] instead of reading a normed operand
-void moe(nvl_model* m, const LayerW& l, int M, bool deferred_norm = false) {
+// next_norm_w (decode, dense-masked form only): the down projection carries the NEXT norm (the following layer's attention
+// norm / the final norm) as the deferred-RMSNorm producer — all of K in one workgroup per (weight half-tile, row tile), no
+// slices left for a norm launch to sum; returns true when it did (m->xn / m->rs_part then hold that norm's operand).
+bool moe(nvl_model* m, const LayerW& l, int M, bool deferred_norm = false, const float* next_norm_w = nullptr) {
     const nvl_model_config& c = m->cfg;
     const int E = c.num_experts, k = c.num_experts_per_tok, I = m->F, H = m->H;
     const int pairs = M * k;
@@ -1439,13 +1446,24 @@ void moe(nvl_model* m, const LayerW& l, int M, bool deferred_norm = false) {
         if (deferred_norm) set_deferred_in(m, a);
         m->site = KS_MOE_UP; m->site_bytes = (e_touch * 2 * I * H + (double)M * H + e_touch * M * I) * (double)m->wsize;
         gemm(m, EPI_SWIGLU, false, a, 2.0 * pairs * 2 * I * H);
+        const int nks = (E * I) >> 5, spe = I >> 5;
+        if (next_norm_w && g_moe_defer_down && nks % 64 == 0 && spe % 4 == 0 && nks / 16 <= 4 * spe && nks / 64 <= 32) {
+            // (the launcher's conditions: 16 waves, whole blocks of 4 k-steps inside one expert, <= 4 experts per wave)
+            GemmArgs d = mk(m->moe_hall, E * I, l.moe_out_cat, m->x, H, nullptr, m->resid_alpha, M, H, E * I);
+            d.moe_gate = m->moe_gate; d.moe_E = E; d.moe_I = I;
+            d.nrm_w = next_norm_w; d.nrm_xn = (bf16_t*)m->xn; d.rs_out = m->rs_part; d.m_split = 1;
+            d.rs_half = defer_half(m, M) ? 1 : 0;
+            m->site = KS_MOE_DOWN; m->site_bytes = (e_touch * H * I + e_touch * M * I) * (double)m->wsize + (double)M * H * 10.0;
+            gemm(m, EPI_RESID, true, d, 2.0 * pairs * H * I);
+            return true;
+        }
         GemmArgs d = mk(m->moe_hall, E * I, l.moe_out_cat, m->x, H, nullptr, 1.f, M, H, E * I);
         const int nsl = moe_down_slices(E);
         d.moe_gate = m->moe_gate; d.moe_E = E; d.moe_I = I; d.sk_part = m->moe_part; d.sk_slices = nsl;
         m->site = KS_MOE_DOWN; m->site_bytes = (e_touch * H * I + e_touch * M * I) * (double)m->wsize + (double)nsl * M * H * 4.0;
         gemm(m, EPI_RESID, true, d, 2.0 * pairs * H * I);
         m->pending_part = m->moe_part; m->pending_slices = nsl; m->pending_rows = M; m->pending_alpha = m->resid_alpha;
-        return;
+        return false;
     }
     // decode-sized batches: one planning launch, and the weighted combine rides on the norm that follows
     const bool small = !m->f32 && M <= 64 && pairs <= MOE_PLAN_MAX_PAIRS && E <= MOE_PLAN_MAX_E && g_moe_small;
@@ -1523,6 +1541,7 @@ void moe(nvl_model* m, const LayerW& l, int M, bool deferred_norm = false) {
                            c.residual_multiplier, m->x, H, 1);
         NVL_HIP(hipGetLastError());
     }
+    return false;
 }
 
 }  // namespace
@@ -1770,14 +1789,16 @@ int enqueue_forward(nvl_model* m, const Meta& md, int n_seqs, int M, int max_len
                 resid_gemm(m, m->attn_out, qw, l.t[NVL_T_WO].p, bo, m->resid_alpha, M, H, qw);
                 norm(m, m->x, nullptr, l.t[NVL_T_FFN_NORM_W], l.t[NVL_T_FFN_NORM_B], m->xn, M);
             }
+            // the FFN-down projection carries the NEXT layer's attention norm, or the final norm when every row is
+            // a last row (decode)
+            const DevTensor* nxt_w = li + 1 < m->L ? &m->layers[li + 1].t[NVL_T_ATTN_NORM_W] : &m->g[NVL_T_FINAL_NORM_W];
+            const DevTensor* nxt_b = li + 1 < m->L ? &m->layers[li + 1].t[NVL_T_ATTN_NORM_B] : &m->g[NVL_T_FINAL_NORM_B];
             if (c.use_moe) {
-                moe(m, l, M, defer);
+                const bool defer2 = defer && defer_moe_ok && g_defer_norm != 3 && !nxt_b->present() &&
+                                    (li + 1 < m->L || (!all_rows && M == n_seqs && M <= 64));
+                xn_deferred = moe(m, l, M, defer, defer2 ? (const float*)nxt_w->p : nullptr);
             } else {
                 ffn_up(m, l, M, defer);
-                // the FFN-down projection carries the NEXT layer's attention norm, or the final norm when every row is
-                // a last row (decode)
-                const DevTensor* nxt_w = li + 1 < m->L ? &m->layers[li + 1].t[NVL_T_ATTN_NORM_W] : &m->g[NVL_T_FINAL_NORM_W];
-                const DevTensor* nxt_b = li + 1 < m->L ? &m->layers[li + 1].t[NVL_T_ATTN_NORM_B] : &m->g[NVL_T_FINAL_NORM_B];
                 const bool defer2 = defer_ok && g_defer_norm != 3 && m->pending_slices == 0 && !nxt_b->present() &&
                                     (li + 1 < m->L || (!all_rows && M == n_seqs && M <= 64));   // (the LM head of a larger batch runs on the tile kernels)
                 m->site = KS_FFN_DOWN;

@@ -273,3 +273,37 @@ def test_full_depth_big_configs(gpu, oracle, capsys, key):
         check_logits(f"{key} bf16 vs fp32 mode, decode step {step}", lb, lf, L, capsys, n_factor=nf)
     hb.close()
     hf.close()
+
+
+def test_moe_down_as_deferred_norm_producer(gpu):
+    """MoE decode, tuning key 33 = 1 (off by default: slower): the experts' down projection keeps all of K in
+    one workgroup — a wave's range covers two experts, streamed block by block through a liveness mask — and carries the next
+    layer's attention norm, so no norm launch sums K slices.  Granite-3.0-1B shapes (the tiny test configs do not meet the
+    form's divisibility conditions), 3 layers, batches of 5 and 24 rows: a decode step against the default form."""
+    import torch
+    from bench import gen_weights_on_device
+    cfg = dict(gpu.synth.FULL_CONFIGS["granite-3.0-1b-a400m"])
+    cfg["num_layers"] = 3
+    cfg["vocab_size"] = 4096
+    rng = np.random.default_rng(5)
+    for B in (5, 24):
+        hm = gpu.HipTransformerModel(cfg, None, precision="bf16", max_seqs=B, max_batch_tokens=B * 32)
+        gen_weights_on_device(gpu, cfg, hm, torch, torch.device("cuda", 0), keep_host=False)
+        hm.finalize()
+        ids = list(range(B))
+        prompts = [rng.integers(0, cfg["vocab_size"], 20).tolist() for _ in ids]
+        forced = [int(t) for t in rng.integers(0, cfg["vocab_size"], B)]
+        got = {}
+        for key33 in (0, 1):
+            old = gpu.lib().nvl_set_tuning(33, key33)
+            try:
+                for i in ids:
+                    hm.seq_reset(i)
+                hm.forward_batch(ids, prompts, [0] * B, want_logits=False)
+                got[key33], _ = hm.forward_batch(ids, [[t] for t in forced], [20] * B)
+                hm.reset_stats()
+            finally:
+                gpu.lib().nvl_set_tuning(33, old)
+        assert rel_rms(got[1], got[0]) <= 5e-3 and rel_max(got[1], got[0]) <= 2e-2, B
+        hm.close()
+
