@@ -439,6 +439,11 @@ int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int 
  * key 24: the decode GEMM kernels do not fetch the activation rows >= M of a padded 16-row tile (1, default).
  * key 27: deferred-norm residual projections of <= 16 rows run on 8-row half tiles, twice the workgroups (1, default).
  * key 29: milliseconds a tensor-parallel rank waits for its peers inside a P2P all-reduce before the call fails (default 30000).
+ * key 30: Mamba2 prefill scan: 1 (default) the chunked SSD form on MFMA, chunks of a sequence in parallel when few (sequence, head)
+ * pairs; 2 the chunked form, chunk after chunk only; 0 the sequential recurrence.
+ * key 31: MoE decode routing (router logits, softmax, top-k, gate matrix) as one launch (1, default; 0 = router GEMM + gate kernel).
+ * key 33: MoE decode: the experts' down projection carries the next RMSNorm (no K slices, no norm launch before the next QKV);
+ * 0 (default): measured slower (rejected list (27)).
  * The settings are PROCESS-GLOBAL and unsynchronised (every model in the process sees them): set them from one thread
  * while no forward call is running.  Every call starts a new tuning epoch: captured decode graphs bake the tuning in and are re-captured.
  * Returns the previous value. */
