@@ -53,6 +53,7 @@ struct AttnArgs {
     float* part;
     int32_t* part_cnt;    // zero between launches
     unsigned long long* stamps;   // diagnostic runs: per-workgroup time stamps (common.h nvl_stamp), else NULL
+    int kv_nt;                    // decode: non-temporal K/V loads (set by the host: attention() in nvllm.hip)
 };
 template <int HD> constexpr int attn_part_floats() { return (HD / 16) * 64 * 4 + 32; }
 
@@ -509,7 +510,12 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(const int32_t
     bf16x8 kf[NT2][4][KS];
     bf16x8 vch[NT2][NVL];
     // the K / V loads of one round (NT2 tiles of this wave): addresses depend on scalars only
-    auto issue_round = [&](int kt0) {
+    // NT: non-temporal loads (AttnArgs::kv_nt, chosen by the host) — a (sequence, kv head)'s K/V are read ONCE per step when
+    // one workgroup serves the whole group (GQA / MHA), and lines that stay out of L2 leave it to the projections'
+    // activations: decode +5 % at B = 32 (32.0 K -> 33.7 K tok/s), GPT-2 B = 128 +3.2 %; it loses 2 % at 32-64 workgroups
+    // (profiles/r03_kv_nontemporal.txt).  Falcon's MQA (5 workgroups share one K/V stream through L2) keeps the default policy.
+    auto issue_round_t = [&](int kt0, auto nt_tag) {
+        constexpr bool NT = decltype(nt_tag)::value;
 #pragma unroll
         for (int h = 0; h < NT2; h++) {
             const int kt = kt0 + h * nvw;
@@ -523,10 +529,19 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(const int32_t
             for (int t = 0; t < 4; t++)
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++)
-                    kf[h][t][ks] = *(const bf16x8*)(kbase + (int64_t)(t * 16 + fq) * HD + ks * 32 + fg * 8);
+                {
+                    const bf16x8* src = (const bf16x8*)(kbase + (int64_t)(t * 16 + fq) * HD + ks * 32 + fg * 8);
+                    if constexpr (NT) kf[h][t][ks] = __builtin_nontemporal_load(src); else kf[h][t][ks] = *src;
+                }
 #pragma unroll
-            for (int i = 0; i < NVL; i++) vch[h][i] = *(const bf16x8*)(vbase + (int64_t)lane * 8 + i * 512);   // 1 KiB, contiguous
+            for (int i = 0; i < NVL; i++) {                                                                 // 1 KiB, contiguous
+                const bf16x8* src = (const bf16x8*)(vbase + (int64_t)lane * 8 + i * 512);
+                if constexpr (NT) vch[h][i] = __builtin_nontemporal_load(src); else vch[h][i] = *src;
+            }
         }
+    };
+    auto issue_round = [&](int kt0) {
+        if (p.kv_nt) issue_round_t(kt0, std::true_type{}); else issue_round_t(kt0, std::false_type{});
     };
     // Load order (vector loads return in issue order): the new token's fp32 q/k/v row + cos/sin FIRST (a dozen small loads),
     // the round's K/V stream right behind them with no wait in between, THEN the RoPE arithmetic — it waits for the row only

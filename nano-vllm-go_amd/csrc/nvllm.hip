@@ -1086,6 +1086,7 @@ static int g_use_graphs = 1;   // nvl_set_tuning key 21: hipGraph replay of deco
 static int g_tune_epoch = 0;   // bumped by every nvl_set_tuning: captured graphs bake the tuning in (part of their key)
 static int g_attn_nw = 0;      // nvl_set_tuning key 15: waves per decode-attention workgroup (0 = from the context length, 2, 4, 8)
 static int g_attn_tq2 = 1;     // nvl_set_tuning key 10: unused since round 2 (the prefill kernel always keeps two sub-tiles per wave)
+static int g_attn_kv_nt = 1;   // nvl_set_tuning key 35: non-temporal K/V loads in the decode attention (0 never, 1 automatic, 2 always)
 static int g_attn_split = 1;   // nvl_set_tuning key 25: split a decode attention's keys over up to 8 workgroups per (sequence, kv head) (0 = never)
 // Launch shape of the decode attention for the batch being enqueued (also part of a captured graph's key): waves per
 // workgroup | workgroups per (sequence, kv head) << 8.
@@ -1135,6 +1136,10 @@ void attention(nvl_model* m, int li, const Meta& md, int n_seqs, int max_len, do
         // fills the chip (>= 2 workgroups per CU) fewer, longer-running waves stream better than many short ones
         // (profiles/r01g_decode_attention_waves.txt).  ctx_hint = the batch's longest context when the caller knows it.
         const int nw = cfg & 255;
+        // non-temporal K/V loads when one workgroup serves a (sequence, kv head)'s whole group (the K/V are then read once) and
+        // the launch fills the chip — by batch size on Llama-3.2-1B (8 kv heads, 520 keys; profiles/r03_kv_nontemporal.txt):
+        // B = 1 +1.7 %, 2 +-0, 4 -2.3 %, 8 -2.4 %, 16 +-0, 24 +2.7 %, 32 +5 %, 48 +1 %; GPT-2 B = 128 (1536 workgroups) +3.2 %
+        a.kv_nt = g_attn_kv_nt == 2 || (g_attn_kv_nt == 1 && cdiv(m->group, 16) == 1 && (m->nKV * n_seqs >= 160 || n_seqs == 1));
         a.stamps = (fused_qkv && m->hd == 64) ? next_stamps(m, KS_ATTN, (int)(grid.x * grid.y * grid.z)) : nullptr;
         if (fused_qkv) {   // RoPE + KV append + attention in one launch, straight from the QKV projection's fp32 output
             a.qkv = m->qkv; a.qkv_stride = m->n_qkv; a.cos_t = m->rope_cos; a.sin_t = m->rope_sin;
