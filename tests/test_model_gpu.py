@@ -353,6 +353,33 @@ def test_graph_replayed_decode_is_bit_identical_to_eager(gpu, oracle, family):
     hm.close()
 
 
+@pytest.mark.parametrize("family", ["llama", "gpt2", "falcon"])
+def test_decode_attention_nontemporal_kv_is_bit_identical(gpu, oracle, family):
+    """Decode attention fetches K/V with non-temporal loads when the launch fills the chip (AttnArgs::kv_nt, tuning key 35):
+    a cache policy, not arithmetic — forced on (2) and off (0) the logits of decode steps must be bit-identical (GQA, MHA,
+    and Falcon's MQA, whose five workgroups per sequence take the flag only when forced)."""
+    cfg, om, hm = build(gpu, oracle, family, "bf16")
+    r = np.random.default_rng(41)
+    prompts = [r.integers(0, cfg["vocab_size"], n).tolist() for n in (70, 9, 33)]
+    got = {}
+    for nt in (2, 0):
+        old = gpu.lib().nvl_set_tuning(35, nt)
+        try:
+            for i in range(3):
+                hm.seq_reset(i)
+            _, am = hm.forward_batch([0, 1, 2], prompts, [0, 0, 0])
+            out, pos = [], [len(p) for p in prompts]
+            for _ in range(5):
+                lg, am = hm.forward_batch([0, 1, 2], [[int(t)] for t in am], pos)
+                out.append(lg.copy()); pos = [p + 1 for p in pos]
+            got[nt] = out
+        finally:
+            gpu.lib().nvl_set_tuning(35, old)
+    for a, b in zip(got[2], got[0]):
+        assert np.array_equal(a, b)
+    hm.close()
+
+
 def test_moe_decode_routing_one_launch_matches_two(gpu, oracle):
     """MoE decode routing (moe.go:57-103): gemm.h moe_router_gate_kernel — router logits, softmax, top-k and the dense gate
     matrix in one launch — against the router as its own skinny GEMM followed by moe_gate_kernel (tuning key 31 = 0).  The
