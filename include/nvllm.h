@@ -444,6 +444,8 @@ int nvl_bench_gemm(int device, int M, int N, int K, int epi, int force_bnt, int 
  * key 31: MoE decode routing (router logits, softmax, top-k, gate matrix) as one launch (1, default; 0 = router GEMM + gate kernel).
  * key 35: non-temporal K/V loads in the decode attention: 1 (default) when one workgroup serves a kv head's group and the launch
  * fills the chip (>= 160 workgroups) or the batch is one sequence; 0 never; 2 always.
+ * key 36: weight tiles per wave of the wide decode projections (FFN-up, LM head): 0 (default) 2 for 17..32 rows and N < 65536, else 4;
+ * 2 / 4 forced.
  * key 33: MoE decode: the experts' down projection carries the next RMSNorm (no K slices, no norm launch before the next QKV);
  * 0 (default): measured slower (rejected list (27)).
  * The settings are PROCESS-GLOBAL and unsynchronised (every model in the process sees them): set them from one thread

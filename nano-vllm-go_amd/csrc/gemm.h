@@ -1220,9 +1220,17 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
 #undef NVL_SKM
     return true;
 }
-template <int EPI, typename OutT>
+// Weight tiles per wave of the wide form (nvl_set_tuning key 36: 0 automatic, 2 / 4 forced).  Four tiles per wave quarter the
+// activation fetches per weight byte, but an FFN-up launch is then only 256 workgroups of 2 waves — 64 KiB of weights in
+// flight per CU.  Two tiles per wave (512 workgroups) for batches of 17..32 rows: Llama-3.2-1B B=32 decode 33.7 K -> 34.5 K
+// tok/s (+2.4 %), B=20 +3.1 %, Falcon-7B B=32 +4.7 %, Llama-3-8B / Granite B=32 +0.8 %; the LM head (thousands of groups
+// either way) is indifferent, and 64-row launches (MT = 4) lose 2 % (profiles/r03_wide_tiles_per_wave.txt).
+static int g_wide_ntb = 0;
+template <int EPI, typename OutT, int NTB = 4>
 static inline bool launch_gemm_skinny_wide(hipStream_t st, const GemmArgs& a) {
-    constexpr int NTB = 4;
+    if constexpr (NTB == 4) {
+        if (g_wide_ntb == 2 || (g_wide_ntb == 0 && skinny_rows(a) <= 32 && a.N < 65536)) return launch_gemm_skinny_wide<EPI, OutT, 2>(st, a);
+    }
     if (a.K % 32 != 0 || a.sk_part) return false;
     const int groups = cdiv(cdiv(a.N, 16), NTB);     // weight rows are padded to 256: every tile of a group exists
     const int MT = skinny_rows(a) <= 16 ? 1 : (skinny_rows(a) <= 32 ? 2 : 4);

@@ -426,5 +426,6 @@ extern "C" int nvl_set_tuning(int key, int value) {
     if (key == 31) { const int old = g_moe_fused_route; g_moe_fused_route = value; return old; }
     if (key == 33) { const int old = g_moe_defer_down; g_moe_defer_down = value; return old; }
     if (key == 35) { const int old = g_attn_kv_nt; g_attn_kv_nt = value; return old; }
+    if (key == 36) { const int old = g_wide_ntb; g_wide_ntb = value; return old; }
     return -1;
 }

@@ -50,7 +50,7 @@ check(r"attn_decode_bf16_kernelILi128ELi8ELb[01]ELb0E", "decode attention hd 128
 # decode projections: the 64-row-group instantiations (PASSES) and the wide form
 check(r"gemm_skinny_bf16_kernelILi4ELi[124]ELi2ELi[0-4]E\w+Lb1ELb0ELb0E", "narrow projection, 64-row groups", lambda r: r["spill"] <= 12)
 check(r"gemm_skinny_bf16_kernelILi[12]ELi[124]ELi4ELi[0-4]E\w+Lb0ELb0ELb[01]E", "narrow projection, <= 32 rows", lambda r: r["spill"] <= 12)
-check(r"gemm_skinny_wide_bf16_kernelILi[12]ELi4ELi4E", "wide projection, <= 32 rows", lambda r: r["spill"] <= 12)
+check(r"gemm_skinny_wide_bf16_kernelILi[12]ELi[24]ELi4E", "wide projection, <= 32 rows", lambda r: r["spill"] <= 12)
 sys.exit(1 if bad else 0)
 PY
 exit $rc
