@@ -1194,7 +1194,12 @@ static inline bool launch_gemm_skinny_ntw(hipStream_t st, const GemmArgs& a) {
     // shorten each wave's stream below the depth of its two-block pipeline (r01 sweeps: LM head, W1)
     int ksplit = 16;
     if (g_force_ksplit) ksplit = g_force_ksplit;
-    else while (ksplit > 1 && (int64_t)nblocks * KS * NTW * ksplit > g_narrow_waves) ksplit >>= 1;
+    else {
+        // (the MoE gate/up projection counts every expert's workgroups, but those of experts no token picked exit at once:
+        //  twice the budget — Granite-1B B=8 decode 6.50 K -> 6.60 K tok/s, profiles/r03_moe_decode_experiments.txt)
+        const int64_t budget = (int64_t)g_narrow_waves * ((a.moe_gate && EPI == EPI_SWIGLU) ? 2 : 1);
+        while (ksplit > 1 && (int64_t)nblocks * KS * NTW * ksplit > budget) ksplit >>= 1;
+    }
     while (ksplit > 1 && ((a.K >> 5) / (ksplit * KS) < U || ksplit * NTW > 16)) ksplit >>= 1;   // >= one block of U k-steps per wave
     if (a.moe_gate && EPI == EPI_RESID) {      // MoE down: every wave's K range is exactly one expert (the skip test needs it)
         ksplit = a.moe_E / KS;
